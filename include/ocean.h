@@ -1,0 +1,159 @@
+/*
+ * include/ocean.h -- C ABI of libocean_hip.so, the MI355X (gfx950) Tessendorf
+ * FFT ocean synthesiser that replaces the reference's CPU path
+ *     class WSTessendorf   (/root/reference/src/scene/WSTessendorf.{h,cpp})
+ * behind the same "Prepare / ComputeWaves / read displacement + normal map"
+ * contract.  The reference has no FFI layer (a plain C++ class with one caller,
+ * src/scene/WaterSurfaceMesh.cpp); this header is the boundary a maintainer
+ * binds instead, and include/WSTessendorf.hpp is the source-compatible C++
+ * adaptor on top of it.  Each entry point cites the reference interface it
+ * replaces.  Plain pointers and sizes only; no exceptions cross the ABI.
+ *
+ * Conventions
+ *   - every function returns OCEAN_OK (0) or a negative OCEAN_E_* code unless
+ *     documented otherwise; ocean_strerror() names them.
+ *   - one context = T independent tiles of the same size N on one device,
+ *     one HIP stream; a context is not re-entrant (like the reference object,
+ *     which shares FFTW buffers: WSTessendorf.cpp:164-171).
+ *   - maps are tightly packed row-major N x N RGBA32F, texel (m, n) at
+ *     float offset 4*(m*N + n): exactly the layout WaterSurfaceMesh.cpp:701-755
+ *     memcpy's into its staging buffer.
+ *       displacement = (lambda*Dx, height/A, lambda*Dz, 1)   WSTessendorf.cpp:380-412,443-455
+ *       normal       = (dh/dx, dh/dz, dDx/dx, dDz/dz)        WSTessendorf.cpp:414-437
+ *   - there is NO CPU fallback: every call fails with OCEAN_E_NO_DEVICE /
+ *     OCEAN_E_HIP when no gfx950 device is usable.
+ */
+#ifndef OCEAN_H_
+#define OCEAN_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCEAN_ABI_VERSION 1
+
+enum {
+    OCEAN_OK            =  0,
+    OCEAN_E_INVALID     = -1,   /* bad argument (null, non power-of-two size, ...)     */
+    OCEAN_E_NO_DEVICE   = -2,   /* no HIP device / wrong architecture                   */
+    OCEAN_E_HIP         = -3,   /* a HIP runtime call failed; see ocean_last_hip_error  */
+    OCEAN_E_NOT_READY   = -4,   /* ocean_compute_waves before ocean_prepare             */
+    OCEAN_E_NOMEM       = -5,
+    OCEAN_E_UNSUPPORTED = -6    /* tile size outside [16, 4096]                         */
+};
+
+typedef struct ocean_ctx ocean_t;
+
+/* Physical parameters of one tile; defaults = WSTessendorf.h:36-43,181.       */
+typedef struct ocean_params {
+    float tile_length;      /* L, metres            (ctor arg, WSTessendorf.h:66)  */
+    float wind_dir_x;       /* any non-zero vector; normalised like .cpp:476-479   */
+    float wind_dir_y;
+    float wind_speed;       /* clamped to >= 1e-4   (.cpp:481-484)                  */
+    float anim_period;      /* T, seconds           (.cpp:486-490)                  */
+    float phillips_const;   /* A                    (.cpp:492-495)                  */
+    float damping;          /* l                    (.cpp:502-505)                  */
+    float lambda;           /* choppiness, default -1 (.h:181, .cpp:497-500)        */
+} ocean_params;
+
+/* Fills *p with the reference defaults (L=1000, wind=(1,1), V=30, T=200,
+ * A=3e-7, l=0.1, lambda=-1).                                                     */
+void ocean_default_params(ocean_params* p);
+
+const char* ocean_strerror(int code);
+int         ocean_abi_version(void);
+/* hipError_t value of the most recent failing HIP call on this thread (0 if none). */
+int         ocean_last_hip_error(void);
+
+/* ---- lifetime: replaces WSTessendorf::WSTessendorf / ~WSTessendorf
+ *      (WSTessendorf.cpp:13-34).  tile_size must be a power of two in
+ *      [16, 4096] (.cpp:459-468 rejects non powers of two); tiles >= 1.
+ *      device = HIP device ordinal.                                              */
+int  ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device);
+void ocean_destroy(ocean_t* ctx);
+
+/* ---- properties: replace the Set.../Get... pairs (WSTessendorf.h:82-122,
+ *      .cpp:459-505).  tile = index in [0, tiles) or OCEAN_ALL_TILES.  Like the
+ *      reference, everything except lambda takes effect at the next
+ *      ocean_prepare; lambda at the next ocean_compute_waves.                    */
+#define OCEAN_ALL_TILES 0xFFFFFFFFu
+int ocean_set_params(ocean_t* ctx, uint32_t tile, const ocean_params* p);
+int ocean_get_params(const ocean_t* ctx, uint32_t tile, ocean_params* p);
+int ocean_set_lambda(ocean_t* ctx, uint32_t tile, float lambda);
+/* Re-sizes every tile (SetTileSize, .cpp:459-468); invalidates prepare.          */
+int ocean_set_tile_size(ocean_t* ctx, uint32_t tile_size);
+uint32_t ocean_tile_size(const ocean_t* ctx);
+uint32_t ocean_tiles(const ocean_t* ctx);
+
+/* ---- Prepare(): WSTessendorf.cpp:36-58 (wave vectors :60-85, gaussian draws
+ *      :87-103, Phillips base spectrum + dispersion :105-148, FFT set-up
+ *      :150-247), all on the device.  Tile i uses seed + i.  xi_or_null: host
+ *      pointer to tiles*N*N*2 floats (re, im) row-major to inject the N(0,1)
+ *      draws instead of generating them (the reference's own draws are
+ *      clock-seeded and not reproducible).                                       */
+int ocean_prepare(ocean_t* ctx, uint64_t seed, const float* xi_or_null);
+
+/* ---- ComputeWaves(t): WSTessendorf.cpp:284-455.
+ *      ocean_compute_waves        : synchronous; writes the height amplitude A
+ *                                   of every tile to out_amp[tiles] (may be NULL)
+ *                                   -- the reference's return value.
+ *      ocean_compute_waves_async  : enqueues the frame on the context's stream
+ *                                   and returns; results are valid after
+ *                                   ocean_synchronize (or stream order).
+ *      t_offsets_or_null: device-resident per-tile time offsets are set with
+ *      ocean_set_time_offsets; tile i is evaluated at t + offset[i].             */
+int ocean_compute_waves(ocean_t* ctx, float t, float* out_amp);
+int ocean_compute_waves_async(ocean_t* ctx, float t);
+int ocean_set_time_offsets(ocean_t* ctx, const float* offsets_or_null /* tiles */);
+int ocean_synchronize(ocean_t* ctx);
+
+/* A, min, max of the last completed frame (GetMinHeight/GetMaxHeight,
+ * WSTessendorf.h:91-92; A = ComputeWaves' return).  Synchronises.               */
+int ocean_get_heights(ocean_t* ctx, uint32_t tile, float* amp, float* min_h, float* max_h);
+
+/* ---- read-out: replaces GetDisplacements()/GetNormals() + the two memcpy's
+ *      of WaterSurfaceMesh.cpp:701-755.  Host destinations (e.g. the mapped
+ *      Vulkan staging pointer); N*N*4 floats per tile, tile-major.  Either may
+ *      be NULL.  Synchronous.                                                    */
+int ocean_read_maps(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);
+
+/* Device pointers of the maps of tile 0 (tile i at +i*N*N*4 floats): zero-copy
+ * hand-off to a device-side consumer (interop, RCCL gather).                     */
+int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
+
+/* Make the context write its maps into caller-owned device memory
+ * (tiles*N*N*4 floats each, 16-byte aligned), e.g. tensors owned by the
+ * harness so a collective can send them without a copy.  NULL restores the
+ * internal buffers.                                                              */
+int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
+
+/* The hipStream_t the context enqueues on (as void*), and a way to replace it
+ * with a caller-owned stream (NULL = back to the context's own).                 */
+void* ocean_stream(ocean_t* ctx);
+int   ocean_set_stream(ocean_t* ctx, void* hip_stream);
+
+/* ---- introspection for tests and the bench -------------------------------- */
+/* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */
+int ocean_read_spectrum(ocean_t* ctx, uint32_t tile, float* h0, float* omega);
+/* Copies the generated gaussian draws of one tile (N*N*2).                      */
+int ocean_read_xi(ocean_t* ctx, uint32_t tile, float* xi);
+
+/* Times `frames` back-to-back frames (t = t0 + j*dt) with HIP events on the
+ * context's stream after `warmup` untimed ones.  ms_total = whole timed region;
+ * ms_kernel[3] = mean duration per launch of {row pass, height column pass,
+ * map column pass}, measured with events bracketing each launch on a second,
+ * separately timed run of the same frames.  Any output pointer may be NULL.     */
+int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
+                      float* ms_total, float* ms_kernel /* [3] */);
+
+/* Algorithmic HBM bytes per texel of the implemented pipeline (SURVEY.md
+ * section 8d accounting; 108 for the seven-field mode).                          */
+int ocean_algorithmic_bytes_per_texel(const ocean_t* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCEAN_H_ */

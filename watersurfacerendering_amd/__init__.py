@@ -1,0 +1,252 @@
+"""watersurfacerendering_amd -- MI355X-native Tessendorf FFT ocean synthesiser.
+
+Host-side mirror of the reference's `class WSTessendorf`
+(/root/reference/src/scene/WSTessendorf.h:58-122) over the C ABI of
+include/ocean.h (libocean_hip.so: hand-written HIP for gfx950).  Same method
+names, argument meaning and (absence of) error behaviour as the reference class
+so parity tests read like calls on the original object:
+
+    ws = WSTessendorf(512, 1000.0)
+    ws.SetWindDirection((1.0, 0.0)); ws.SetWindSpeed(10.0)
+    ws.Prepare(seed=7)
+    A = ws.ComputeWaves(1.5)
+    disp, normals = ws.GetDisplacements(), ws.GetNormals()     # (N, N, 4) float32
+
+`OceanBatch` exposes the batched / asynchronous surface (T independent tiles
+per context, device-resident maps, event timing) the bench and the multi-GPU
+path use.  Nothing here falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from ._abi import OceanError, Params, build  # noqa: F401
+
+__all__ = ["WSTessendorf", "OceanBatch", "OceanError", "build"]
+
+
+def _is_pow2(n: int) -> bool:
+    return n > 0 and (n & (n - 1)) == 0
+
+
+class OceanBatch:
+    """T independent N x N tiles on one device (ocean_create ... ocean_destroy)."""
+
+    def __init__(self, tile_size: int = 512, tiles: int = 1, device: int = 0):
+        self._L = _abi.lib()
+        self._h = C.c_void_p()
+        _abi.check(self._L.ocean_create(C.byref(self._h), tile_size, tiles, device), "ocean_create")
+        self.tiles = tiles
+        self.device = device
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.ocean_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- properties ---------------------------------------------------------------
+    @property
+    def tile_size(self) -> int:
+        return int(self._L.ocean_tile_size(self._h))
+
+    def get_params(self, tile: int = 0) -> Params:
+        p = Params()
+        _abi.check(self._L.ocean_get_params(self._h, tile, C.byref(p)), "ocean_get_params")
+        return p
+
+    def set_params(self, tile: int = _abi.OCEAN_ALL_TILES, **kw):
+        p = self.get_params(0 if tile == _abi.OCEAN_ALL_TILES else tile)
+        for k, v in kw.items():
+            k = "lambda_" if k in ("lambda", "lam") else k
+            if not hasattr(p, k):
+                raise TypeError(f"unknown ocean parameter {k!r}")
+            setattr(p, k, v)
+        _abi.check(self._L.ocean_set_params(self._h, tile, C.byref(p)), "ocean_set_params")
+
+    def set_lambda(self, lam: float, tile: int = _abi.OCEAN_ALL_TILES):
+        _abi.check(self._L.ocean_set_lambda(self._h, tile, lam), "ocean_set_lambda")
+
+    def set_tile_size(self, n: int):
+        _abi.check(self._L.ocean_set_tile_size(self._h, n), "ocean_set_tile_size")
+
+    # -- Prepare / ComputeWaves -----------------------------------------------------
+    def prepare(self, seed: int = 0, xi: np.ndarray | None = None):
+        ptr = None
+        if xi is not None:
+            n = self.tile_size
+            xi = np.ascontiguousarray(xi, dtype=np.float32).reshape(self.tiles, n, n, 2)
+            ptr = xi.ctypes.data_as(C.c_void_p)
+        _abi.check(self._L.ocean_prepare(self._h, seed & 0xFFFFFFFFFFFFFFFF, ptr), "ocean_prepare")
+
+    def compute_waves(self, t: float) -> np.ndarray:
+        amp = np.empty(self.tiles, dtype=np.float32)
+        _abi.check(self._L.ocean_compute_waves(self._h, t, amp.ctypes.data_as(C.POINTER(C.c_float))),
+                   "ocean_compute_waves")
+        return amp
+
+    def compute_waves_async(self, t: float):
+        _abi.check(self._L.ocean_compute_waves_async(self._h, t), "ocean_compute_waves_async")
+
+    def set_time_offsets(self, offsets):
+        if offsets is None:
+            _abi.check(self._L.ocean_set_time_offsets(self._h, None), "ocean_set_time_offsets")
+            return
+        o = np.ascontiguousarray(offsets, dtype=np.float32)
+        assert o.size == self.tiles
+        _abi.check(self._L.ocean_set_time_offsets(self._h, o.ctypes.data_as(C.c_void_p)), "ocean_set_time_offsets")
+
+    def synchronize(self):
+        _abi.check(self._L.ocean_synchronize(self._h), "ocean_synchronize")
+
+    def heights(self, tile: int = 0):
+        a, mn, mx = C.c_float(), C.c_float(), C.c_float()
+        _abi.check(self._L.ocean_get_heights(self._h, tile, C.byref(a), C.byref(mn), C.byref(mx)),
+                   "ocean_get_heights")
+        return a.value, mn.value, mx.value
+
+    # -- read-out -------------------------------------------------------------------
+    def read_maps(self, first: int = 0, count: int | None = None):
+        count = self.tiles - first if count is None else count
+        n = self.tile_size
+        d = np.empty((count, n, n, 4), dtype=np.float32)
+        q = np.empty((count, n, n, 4), dtype=np.float32)
+        _abi.check(self._L.ocean_read_maps(self._h, first, count, d.ctypes.data_as(C.c_void_p),
+                                           q.ctypes.data_as(C.c_void_p)), "ocean_read_maps")
+        return d, q
+
+    def device_maps(self):
+        d, q = C.c_void_p(), C.c_void_p()
+        _abi.check(self._L.ocean_device_maps(self._h, C.byref(d), C.byref(q)), "ocean_device_maps")
+        return d.value, q.value
+
+    def bind_output(self, d_disp: int | None, d_nrm: int | None):
+        _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")
+
+    @property
+    def stream(self) -> int:
+        return self._L.ocean_stream(self._h) or 0
+
+    def set_stream(self, s: int | None):
+        _abi.check(self._L.ocean_set_stream(self._h, C.c_void_p(s)), "ocean_set_stream")
+
+    def read_spectrum(self, tile: int = 0):
+        n = self.tile_size
+        h0 = np.empty((n, n, 2), dtype=np.float32)
+        om = np.empty((n, n), dtype=np.float32)
+        _abi.check(self._L.ocean_read_spectrum(self._h, tile, h0.ctypes.data_as(C.c_void_p),
+                                               om.ctypes.data_as(C.c_void_p)), "ocean_read_spectrum")
+        return h0, om
+
+    def read_xi(self, tile: int = 0):
+        n = self.tile_size
+        xi = np.empty((n, n, 2), dtype=np.float32)
+        _abi.check(self._L.ocean_read_xi(self._h, tile, xi.ctypes.data_as(C.c_void_p)), "ocean_read_xi")
+        return xi
+
+    def time_frames(self, t0: float, dt: float, warmup: int, frames: int, per_kernel: bool = True):
+        """(ms_total, [ms_rows, ms_height, ms_maps]) measured with HIP events on the context's stream."""
+        total = C.c_float()
+        k = (C.c_float * 3)()
+        _abi.check(self._L.ocean_time_frames(self._h, t0, dt, warmup, frames, C.byref(total),
+                                             k if per_kernel else None), "ocean_time_frames")
+        return total.value, [k[0], k[1], k[2]] if per_kernel else None
+
+    @property
+    def algorithmic_bytes_per_texel(self) -> int:
+        return int(self._L.ocean_algorithmic_bytes_per_texel(self._h))
+
+
+class WSTessendorf:
+    """Drop-in mirror of the reference class (WSTessendorf.h:58-122).
+
+    Like the reference: setters other than SetLambda take effect at the next
+    Prepare(); SetTileSize silently ignores a non power of two
+    (WSTessendorf.cpp:459-468); nothing raises for "wrong order" except calling
+    ComputeWaves before Prepare, which the reference would crash on.
+    Prepare() with no seed draws a fresh one, as the reference re-randomises on
+    every Prepare (WSTessendorf.cpp:87-103 + core/Application.cpp:21).
+    """
+
+    s_kDefaultTileSize = 512
+    s_kDefaultTileLength = 1000.0
+    s_kDefaultWindDir = (1.0, 1.0)
+    s_kDefaultWindSpeed = 30.0
+    s_kDefaultAnimPeriod = 200.0
+    s_kDefaultPhillipsConst = 3e-7
+    s_kDefaultPhillipsDamping = 0.1
+
+    def __init__(self, tileSize: int = 512, tileLength: float = 1000.0, device: int = 0):
+        if not _is_pow2(tileSize):
+            tileSize = self.s_kDefaultTileSize
+        self._b = OceanBatch(tileSize, 1, device)
+        self._b.set_params(tile_length=tileLength)
+        self._disp = None
+        self._nrm = None
+        self._min = -1.0   # WSTessendorf.h:227-228
+        self._max = 1.0
+        self._seed_ctr = 0
+
+    # -- Prepare / ComputeWaves (WSTessendorf.cpp:36-58, 284-455) -------------------
+    def Prepare(self, seed: int | None = None, xi: np.ndarray | None = None):
+        if seed is None:
+            import time
+            self._seed_ctr += 1
+            seed = (time.time_ns() ^ (self._seed_ctr * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        self._b.prepare(seed, xi)
+        n = self._b.tile_size
+        self._disp = np.zeros((n, n, 4), dtype=np.float32)            # .cpp:48-51
+        self._nrm = np.zeros((n, n, 4), dtype=np.float32)
+        self._nrm[..., 1] = 1.0                                        # .cpp:53-54
+
+    def ComputeWaves(self, time: float) -> float:
+        amp = float(self._b.compute_waves(time)[0])
+        d, q = self._b.read_maps(0, 1)
+        self._disp, self._nrm = d[0], q[0]
+        _, self._min, self._max = self._b.heights(0)
+        return amp
+
+    # -- getters (WSTessendorf.h:82-107) ----------------------------------------------
+    def GetTileSize(self): return self._b.tile_size
+    def GetTileLength(self): return self._b.get_params().tile_length
+
+    def GetWindDir(self):
+        p = self._b.get_params()
+        inv = 1.0 / math.sqrt(p.wind_dir_x ** 2 + p.wind_dir_y ** 2)
+        return (p.wind_dir_x * inv, p.wind_dir_y * inv)
+
+    def GetWindSpeed(self): return max(1e-4, self._b.get_params().wind_speed)
+    def GetAnimationPeriod(self): return self._b.get_params().anim_period
+    def GetPhillipsConst(self): return self._b.get_params().phillips_const
+    def GetDamping(self): return self._b.get_params().damping
+    def GetDisplacementLambda(self): return self._b.get_params().lambda_
+    def GetMinHeight(self): return self._min
+    def GetMaxHeight(self): return self._max
+    def GetDisplacementCount(self): return 0 if self._disp is None else self._disp.shape[0] * self._disp.shape[1]
+    def GetDisplacements(self): return self._disp
+    def GetNormalCount(self): return 0 if self._nrm is None else self._nrm.shape[0] * self._nrm.shape[1]
+    def GetNormals(self): return self._nrm
+
+    # -- setters (WSTessendorf.cpp:459-505) ----------------------------------------------
+    def SetTileSize(self, size: int):
+        if not _is_pow2(size):
+            return                      # .cpp:463-467: ignored
+        self._b.set_tile_size(size)
+
+    def SetTileLength(self, length: float): self._b.set_params(tile_length=length)
+    def SetWindDirection(self, w): self._b.set_params(wind_dir_x=float(w[0]), wind_dir_y=float(w[1]))
+    def SetWindSpeed(self, v: float): self._b.set_params(wind_speed=max(1e-4, v))
+    def SetAnimationPeriod(self, T: float): self._b.set_params(anim_period=T)
+    def SetPhillipsConst(self, A: float): self._b.set_params(phillips_const=A)
+    def SetLambda(self, lam: float): self._b.set_lambda(lam)
+    def SetDamping(self, damping: float): self._b.set_params(damping=damping)

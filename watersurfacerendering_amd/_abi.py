@@ -1,0 +1,127 @@
+"""ctypes binding of include/ocean.h (libocean_hip.so).
+
+The product path is HIP only: importing this module never touches oracle/, and
+every call raises OceanError when the extension or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libocean_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+OCEAN_OK = 0
+OCEAN_E_INVALID = -1
+OCEAN_E_NO_DEVICE = -2
+OCEAN_E_HIP = -3
+OCEAN_E_NOT_READY = -4
+OCEAN_E_NOMEM = -5
+OCEAN_E_UNSUPPORTED = -6
+OCEAN_ALL_TILES = 0xFFFFFFFF
+
+#: every symbol include/ocean.h declares (tests check the .so exports each one)
+SYMBOLS = [
+    "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_last_hip_error",
+    "ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_set_lambda",
+    "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
+    "ocean_compute_waves", "ocean_compute_waves_async", "ocean_set_time_offsets", "ocean_synchronize",
+    "ocean_get_heights", "ocean_read_maps", "ocean_device_maps", "ocean_bind_output",
+    "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
+    "ocean_time_frames", "ocean_algorithmic_bytes_per_texel",
+]
+
+
+class OceanError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what}: {strerror(code)} (code {code}, hip {last_hip_error()})")
+        self.code = code
+
+
+class Params(C.Structure):
+    """struct ocean_params (include/ocean.h)."""
+    _fields_ = [("tile_length", C.c_float), ("wind_dir_x", C.c_float), ("wind_dir_y", C.c_float),
+                ("wind_speed", C.c_float), ("anim_period", C.c_float), ("phillips_const", C.c_float),
+                ("damping", C.c_float), ("lambda_", C.c_float)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("ocean_api.hip", "ocean_kernels.h", "fft_engine.h", "Makefile")]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the extension.  Fails loudly if it has not been built: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the ocean synthesis path.")
+    L = C.CDLL(LIB_PATH)
+    P, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
+    FP = C.POINTER(C.c_float)
+    sig = {
+        "ocean_default_params": (None, [C.POINTER(Params)]),
+        "ocean_strerror": (C.c_char_p, [i32]),
+        "ocean_abi_version": (i32, []),
+        "ocean_last_hip_error": (i32, []),
+        "ocean_create": (i32, [C.POINTER(P), u32, u32, i32]),
+        "ocean_destroy": (None, [P]),
+        "ocean_set_params": (i32, [P, u32, C.POINTER(Params)]),
+        "ocean_get_params": (i32, [P, u32, C.POINTER(Params)]),
+        "ocean_set_lambda": (i32, [P, u32, f32]),
+        "ocean_set_tile_size": (i32, [P, u32]),
+        "ocean_tile_size": (u32, [P]),
+        "ocean_tiles": (u32, [P]),
+        "ocean_prepare": (i32, [P, u64, C.c_void_p]),
+        "ocean_compute_waves": (i32, [P, f32, FP]),
+        "ocean_compute_waves_async": (i32, [P, f32]),
+        "ocean_set_time_offsets": (i32, [P, C.c_void_p]),
+        "ocean_synchronize": (i32, [P]),
+        "ocean_get_heights": (i32, [P, u32, FP, FP, FP]),
+        "ocean_read_maps": (i32, [P, u32, u32, C.c_void_p, C.c_void_p]),
+        "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
+        "ocean_bind_output": (i32, [P, P, P]),
+        "ocean_stream": (P, [P]),
+        "ocean_set_stream": (i32, [P, P]),
+        "ocean_read_spectrum": (i32, [P, u32, C.c_void_p, C.c_void_p]),
+        "ocean_read_xi": (i32, [P, u32, C.c_void_p]),
+        "ocean_time_frames": (i32, [P, f32, f32, i32, i32, FP, FP]),
+        "ocean_algorithmic_bytes_per_texel": (i32, [P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def strerror(code: int) -> str:
+    try:
+        return lib().ocean_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def last_hip_error() -> int:
+    try:
+        return lib().ocean_last_hip_error()
+    except Exception:  # pragma: no cover
+        return -1
+
+
+def check(code: int, what: str) -> None:
+    if code != OCEAN_OK:
+        raise OceanError(code, what)

@@ -1,0 +1,230 @@
+// fft_engine.h -- block-level batched complex FFT for gfx950 (CDNA4), fp32.
+//
+// Computes C interleaved length-N unnormalised BACKWARD DFTs
+//     B[X](q) = sum_n X(n) * exp(+2*pi*i*q*n/N)
+// (the transform the reference obtains from fftwf_plan_dft_2d(..., FFTW_BACKWARD, ...),
+//  /root/reference/src/scene/WSTessendorf.cpp:191-232, one axis at a time)
+// with T threads of one workgroup.  Stockham autosort: every stage reads
+// element (j + i*N/R) and writes element ((j-k)*R + k + i*Ns), so
+//   * the FIRST stage takes its inputs from a functor (global loads or values
+//     computed on the fly) -- nothing is staged before the first butterfly,
+//   * the LAST stage hands its outputs, already in natural order and
+//     lane-contiguous, to a functor (coalesced global stores / registers),
+//   * only the (stages-1) exchanges in between go through LDS, in place.
+// Butterflies are radix 4/8/16 held in VGPRs (64-wide waves, no cross-lane
+// traffic); inter-stage twiddles come from one table-loaded base twiddle per
+// butterfly raised to powers in log depth.
+//
+// LDS image: element (idx, c) of the batch lives at  (idx + idx/16) * C + c
+// (float2 units).  The c-fastest interleave keeps every stage's reads
+// lane-contiguous; the +idx/16 padding spreads the scattered writes of the
+// expanding stages over all banks (ds_write_b64: 16-lane groups, 32 banks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ocean {
+
+using c32 = float2;
+
+__device__ __forceinline__ c32 cmul(c32 a, c32 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c32 cmuli(c32 a) { return make_float2(-a.y, a.x); }   // * (+i)
+
+// ---- in-register radix-R backward DFTs, natural order in and out ----------
+__device__ __forceinline__ void dft4(c32& x0, c32& x1, c32& x2, c32& x3)
+{
+    const c32 t0 = cadd(x0, x2), t1 = csub(x0, x2);
+    const c32 t2 = cadd(x1, x3), t3 = cmuli(csub(x1, x3));
+    x0 = cadd(t0, t2); x2 = csub(t0, t2);
+    x1 = cadd(t1, t3); x3 = csub(t1, t3);
+}
+
+template <int R> struct Dft;
+
+template <> struct Dft<2> {
+    static __device__ __forceinline__ void run(c32 (&x)[2])
+    {
+        const c32 a = x[0], b = x[1];
+        x[0] = cadd(a, b); x[1] = csub(a, b);
+    }
+};
+
+template <> struct Dft<4> {
+    static __device__ __forceinline__ void run(c32 (&x)[4]) { dft4(x[0], x[1], x[2], x[3]); }
+};
+
+template <> struct Dft<8> {
+    static __device__ __forceinline__ void run(c32 (&x)[8])
+    {
+        // decimation in time: E = DFT4(even), O = DFT4(odd), y[k] = E[k] + w8^k O[k]
+        dft4(x[0], x[2], x[4], x[6]);
+        dft4(x[1], x[3], x[5], x[7]);
+        constexpr float h = 0.70710678118654752440f;
+        const c32 o0 = x[1];
+        const c32 o1 = make_float2(h * (x[3].x - x[3].y), h * (x[3].x + x[3].y));     // * (1+i)/sqrt2
+        const c32 o2 = cmuli(x[5]);                                                    // * i
+        const c32 o3 = make_float2(-h * (x[7].x + x[7].y), h * (x[7].x - x[7].y));    // * (-1+i)/sqrt2
+        const c32 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
+        x[1] = cadd(e1, o1); x[5] = csub(e1, o1);
+        x[2] = cadd(e2, o2); x[6] = csub(e2, o2);
+        x[3] = cadd(e3, o3); x[7] = csub(e3, o3);
+    }
+};
+
+template <> struct Dft<16> {
+    static __device__ __forceinline__ void run(c32 (&x)[16])
+    {
+        // n = 4a + b, k = k1 + 4 k2:
+        //   Y[k1 + 4 k2] = sum_b w4^(b k2) * [ w16^(b k1) * sum_a x[4a + b] w4^(a k1) ]
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4(x[b], x[b + 4], x[b + 8], x[b + 12]);
+        // now x[b + 4*k1] = u_b[k1]; multiply by w16^(b*k1)
+        constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // w16^1
+        constexpr float h = 0.70710678118654752440f;                                   // w16^2 = (h, h)
+        auto mul = [](c32 v, float cr, float ci) { return make_float2(v.x * cr - v.y * ci, v.x * ci + v.y * cr); };
+        x[1 + 4] = mul(x[1 + 4], c1, s1);        // b=1,k1=1 : w^1
+        x[1 + 8] = mul(x[1 + 8], h, h);          // b=1,k1=2 : w^2
+        x[1 + 12] = mul(x[1 + 12], s1, c1);      // b=1,k1=3 : w^3
+        x[2 + 4] = mul(x[2 + 4], h, h);          // b=2,k1=1 : w^2
+        x[2 + 8] = cmuli(x[2 + 8]);              // b=2,k1=2 : w^4 = i
+        x[2 + 12] = mul(x[2 + 12], -h, h);       // b=2,k1=3 : w^6
+        x[3 + 4] = mul(x[3 + 4], s1, c1);        // b=3,k1=1 : w^3
+        x[3 + 8] = mul(x[3 + 8], -h, h);         // b=3,k1=2 : w^6
+        x[3 + 12] = mul(x[3 + 12], -c1, -s1);    // b=3,k1=3 : w^9
+        // outer DFT4 over b for each k1; result k2 lands at index k1 + 4*k2
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1 + 0], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+        // x[4*k1 + k2] holds Y[k1 + 4*k2]  -> transpose the 4x4 index grid
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                const c32 t = x[4 * p + q]; x[4 * p + q] = x[4 * q + p]; x[4 * q + p] = t;
+            }
+    }
+};
+
+// x[i] *= w1^i, powers built in log depth (<= 4 products deep for R = 16)
+template <int R>
+__device__ __forceinline__ void apply_twiddles(c32 (&x)[R], c32 w1)
+{
+    c32 pw[R];
+    pw[0] = make_float2(1.f, 0.f);
+    pw[1] = w1;
+#pragma unroll
+    for (int i = 2; i < R; ++i) pw[i] = cmul(pw[i / 2], pw[i - i / 2]);
+#pragma unroll
+    for (int i = 1; i < R; ++i) x[i] = cmul(x[i], pw[i]);
+}
+
+// ---- radix plans -------------------------------------------------------------
+template <int N> struct Plan;
+#define OCEAN_PLAN(n, a, b, c) \
+    template <> struct Plan<n> { static constexpr int r0 = a, r1 = b, r2 = c; };
+OCEAN_PLAN(16, 16, 1, 1)
+OCEAN_PLAN(32, 8, 4, 1)
+OCEAN_PLAN(64, 8, 8, 1)
+OCEAN_PLAN(128, 16, 8, 1)
+OCEAN_PLAN(256, 16, 16, 1)
+OCEAN_PLAN(512, 8, 8, 8)
+OCEAN_PLAN(1024, 16, 8, 8)
+OCEAN_PLAN(2048, 16, 16, 8)
+OCEAN_PLAN(4096, 16, 16, 16)
+#undef OCEAN_PLAN
+
+template <int N> struct LastRadix {
+    static constexpr int value = Plan<N>::r2 != 1 ? Plan<N>::r2 : (Plan<N>::r1 != 1 ? Plan<N>::r1 : Plan<N>::r0);
+};
+
+template <int N> constexpr int lds_padded() { return N + N / 16; }
+template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() * C; }
+
+template <int C>
+__device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
+
+// One Stockham stage over the whole batch.
+//   FIRST: inputs from in(idx, c);  otherwise from LDS
+//   LAST : outputs to out(idx, c, value, u, i) (u, i are unrolled constants);
+//          otherwise to LDS, in place (reads complete -> barrier -> writes)
+template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, class In, class Out>
+__device__ __forceinline__ void fft_stage(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
+{
+    constexpr int ITEMS = (N / R) * C;
+    constexpr int IT = (ITEMS + T - 1) / T;
+    constexpr bool GUARD = (ITEMS % T) != 0;
+    c32 x[IT][R];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int w = tid + u * T;
+        if (!GUARD || w < ITEMS) {
+            const int c = w % C, j = w / C;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if constexpr (FIRST) x[u][i] = in(j + i * (N / R), c);
+                else x[u][i] = lds[lds_index<C>(j + i * (N / R), c)];
+            }
+            if constexpr (NS > 1) {
+                const int k = j % NS;
+                apply_twiddles<R>(x[u], tw[k * (N / (NS * R))]);
+            }
+            Dft<R>::run(x[u]);
+        }
+    }
+    if constexpr (!LAST) __syncthreads();   // every reader of the old image is done
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int w = tid + u * T;
+        if (!GUARD || w < ITEMS) {
+            const int c = w % C, j = w / C;
+            const int k = j % NS;
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if constexpr (LAST) out(j0 + i * NS, c, x[u][i], u, i);
+                else lds[lds_index<C>(j0 + i * NS, c)] = x[u][i];
+            }
+        }
+    }
+}
+
+// C interleaved length-N transforms by the T threads of the workgroup.
+// `lds` needs fft_lds_elems<N, C>() float2; `tw[k] = exp(+2 pi i k / N)`.
+// The call may start while other waves still read `lds` from a previous call:
+// the first LDS write is preceded by a barrier.
+template <int N, int C, int T, class In, class Out>
+__device__ __forceinline__ void batch_fft(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
+{
+    constexpr int R0 = Plan<N>::r0, R1 = Plan<N>::r1, R2 = Plan<N>::r2;
+    auto none_in = [](int, int) { return make_float2(0.f, 0.f); };
+    auto none_out = [](int, int, c32, int, int) {};
+    if constexpr (R1 == 1) {
+        fft_stage<N, R0, 1, C, T, true, true>(lds, tw, tid, in, out);
+    } else if constexpr (R2 == 1) {
+        fft_stage<N, R0, 1, C, T, true, false>(lds, tw, tid, in, none_out);
+        __syncthreads();
+        fft_stage<N, R1, R0, C, T, false, true>(lds, tw, tid, none_in, out);
+    } else {
+        fft_stage<N, R0, 1, C, T, true, false>(lds, tw, tid, in, none_out);
+        __syncthreads();
+        fft_stage<N, R1, R0, C, T, false, false>(lds, tw, tid, none_in, none_out);
+        __syncthreads();
+        fft_stage<N, R2, R0 * R1, C, T, false, true>(lds, tw, tid, none_in, out);
+    }
+}
+
+// Mapping of the LAST stage: work item w = tid + u*T owns outputs
+// idx = j + i*(N/RL), column c, with j = w / C, c = w % C (k == j there).
+template <int N, int C, int T> struct LastStage {
+    static constexpr int RL = LastRadix<N>::value;
+    static constexpr int ITEMS = (N / RL) * C;
+    static constexpr int IT = (ITEMS + T - 1) / T;
+    static constexpr bool GUARD = (ITEMS % T) != 0;
+    static constexpr int STRIDE = N / RL;
+};
+
+}  // namespace ocean
