@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ocean synthesiser.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one ComputeWaves(t) of the hot path (reference
+WSTessendorf.cpp:284-455) on synthetic input: a 2048 x 2048 tile, all seven
+output fields, reference default parameters, xi from the counter-based RNG
+with seed 0x5EED0000 + tile_index, t_j = 0.05*j.  Inputs (h0,
+omega) are resident in HBM before the timed region; outputs are the two finished
+RGBA32F maps in HBM (D2H read-back is not part of the metric).
+
+Multi-GPU: tiles are independent, so every rank synthesises its own tile(s)
+with no data-path collective ("weak" scaling, value = frames of all ranks per
+second).  The north-star's single RCCL gather of the packed maps is measured
+separately after the timed region and reported under "gather" (it is
+xGMI-bound and slower than one GPU's synthesis: DESIGN.md section 6).
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x5EED0000
+DT = 0.05
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per texel per launch (sum = 108 = SURVEY 8d)
+KERNEL_BYTES = {"k_rows": 40, "k_cols_height": 8, "k_cols_maps": 60}
+KERNEL_ORDER = ["k_rows", "k_cols_height", "k_cols_maps"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=2048, help="tile size N (default: the roofline config, 2048)")
+    ap.add_argument("--tiles", type=int, default=1, help="independent tiles per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather measurement at N>1")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary 512^2 / batched measurements")
+    return ap.parse_args()
+
+
+def cpu_baseline(n: int, budget_s: float):
+    """The oracle (reference-shaped OpenMP port, own float FFT) timed on the host cores."""
+    from oracle import oracle as O
+    o = O.Oracle(n)
+    o.prepare(seed=SEED)
+    threads = int(O.lib().oracle_num_threads())
+    for j in range(2):
+        o.compute_waves(DT * j, fft=O.FFT_F32, copy=False)
+    times = []
+    t_start = time.perf_counter()
+    j = 0
+    while True:
+        t0 = time.perf_counter()
+        o.compute_waves(DT * (2 + j), fft=O.FFT_F32, copy=False)
+        times.append(time.perf_counter() - t0)
+        j += 1
+        if (time.perf_counter() - t_start >= budget_s and j >= 5) or j >= 200:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{len(times)} frames of the same {n}x{n} 7-field workload after 2 warm-up frames, median "
+                  f"({med * 1e3:.1f} ms/frame); FFTW not available on this host: baseline is the oracle's own "
+                  f"float Stockham FFT in the reference's OpenMP shape (7 single-threaded 2-D FFTs in parallel)",
+        "gtexels_per_s": n * n / med * 1e-9,
+    }
+
+
+def measure_config(W, n, tiles, device, steps, warmup):
+    b = W.OceanBatch(n, tiles, device)
+    b.prepare(SEED)
+    ms, kern = b.time_frames(0.0, DT, warmup, steps, per_kernel=True)
+    per = ms / steps * 1e-3
+    b.close()
+    return {"size": n, "tiles_per_step": tiles, "frames_per_s": tiles / per, "us_per_step": per * 1e6,
+            "gtexels_per_s": n * n * tiles / per * 1e-9, "algorithmic_GBps": 108.0 * n * n * tiles / per * 1e-9,
+            "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern)}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import dist as wdist
+
+    n, tiles = args.size, args.tiles
+    first_tile, _ = wdist.tile_shard(tiles * world, world, rank)
+    b = W.OceanBatch(n, tiles, local_rank)
+    # maps live in a torch tensor so the gather leg can send them without a copy
+    maps = torch.empty((tiles, 2, n, n, 4), dtype=torch.float32, device=dev)
+    if tiles == 1:
+        b.bind_output(maps[0, 0].data_ptr(), maps[0, 1].data_ptr())
+    b.prepare(SEED + first_tile)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def sync():
+        b.synchronize()
+        torch.cuda.synchronize()
+
+    for j in range(args.warmup):
+        b.compute_waves_async(DT * j)
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        b.compute_waves_async(DT * (args.warmup + j))
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    elapsed = wdist.max_over_ranks(elapsed, device=str(dev))
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = world * tiles * args.steps / elapsed
+
+    # ---- dominant-kernel roofline, measured live with HIP events on the launch stream
+    _, kern_ms = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
+    dom = max(range(3), key=lambda i: kern_ms[i])
+    dom_name = KERNEL_ORDER[dom]
+    dom_bytes = KERNEL_BYTES[dom_name] * n * n * tiles
+    achieved = dom_bytes / (kern_ms[dom] * 1e-3) * 1e-9
+    traffic = None
+    traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            ent = tj.get(f"{dom_name}@{n}")
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
+        except Exception:
+            pass
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": dom_bytes, "launch_us": kern_ms[dom] * 1e3,
+                "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern_ms)},
+                "frame_algorithmic_GBps": 108.0 * n * n * tiles / (ms_per_step * 1e-3) * 1e-9,
+                "frame_frac": 108.0 * n * n * tiles / (ms_per_step * 1e-3) * 1e-9 / HBM_PEAK_GBPS}
+
+    # ---- RCCL gather of the packed maps (north-star exchange step), outside the timed region
+    gather = None
+    if world > 1 and not args.no_gather and tiles == 1:
+        reps = 10
+        sync(); barrier()
+        tg = time.perf_counter()
+        for j in range(reps):
+            b.compute_waves_async(DT * j)
+            b.synchronize()
+            wdist.gather_maps(maps, dst=0)
+        torch.cuda.synchronize(); barrier()
+        serial = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=str(dev))
+        gather = {"what": "every step followed by one torch.distributed.gather (RCCL) of the packed maps to rank 0",
+                  "bytes_per_rank": int(maps.numel() * 4), "ms_per_step_serial": serial * 1e3,
+                  "frames_per_s_serial": world * tiles / serial}
+
+    out = None
+    if rank == 0:
+        extra = {}
+        if not args.no_extra and world == 1:
+            b.close()
+            del maps
+            torch.cuda.empty_cache()
+            extra["512x512_single_tile"] = measure_config(W, 512, 1, local_rank, 300, 20)
+            extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
+            extra["1024x1024_batch8"] = measure_config(W, 1024, 8, local_rank, 50, 5)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(n, args.cpu_seconds)
+        out = {
+            "metric": "ocean frames/s (ComputeWaves, 7 fields -> displacement + normal map)",
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}x{n} tile, FULL7 (7 real fields via 3.5 complex 2-D iFFTs), "
+                                   f"{tiles} tile(s) per rank per step, reference default parameters",
+                       "tile_size": n, "tiles_per_rank": tiles, "seed": SEED, "dt": DT,
+                       "parallelism": f"tiles sharded 1 process per GPU x{world}, no data-path collective"},
+            "gtexels_per_s": n * n * frames_per_s * 1e-9,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "speedup_vs_cpu_baseline": (frames_per_s / cpu["value"]) if cpu else None,
+            "gather": gather,
+            "extra": extra,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
