@@ -1,0 +1,123 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/ocean.h declares, and its argument checking / error paths work
+without a GPU.  No compute is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from watersurfacerendering_amd import _abi
+    _abi.build()
+    return _abi
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ocean.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocean_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_list_agree(abi):
+    assert declared_symbols() == sorted(abi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(abi):
+    L = abi.lib()
+    for s in declared_symbols():
+        assert hasattr(L, s), s
+    out = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ocean_[a-z0-9_]+)", out))
+    assert set(declared_symbols()) <= exported
+
+
+def test_abi_version_defaults_and_strerror(abi):
+    L = abi.lib()
+    assert L.ocean_abi_version() == 1
+    p = abi.Params()
+    L.ocean_default_params(C.byref(p))
+    # WSTessendorf.h:36-43,181
+    assert (p.tile_length, p.wind_dir_x, p.wind_dir_y, p.wind_speed, p.anim_period) == (1000.0, 1.0, 1.0, 30.0, 200.0)
+    assert p.phillips_const == pytest.approx(3e-7) and p.damping == pytest.approx(0.1) and p.lambda_ == -1.0
+    for code in range(0, -7, -1):
+        assert L.ocean_strerror(code)
+    assert b"power of two" in L.ocean_strerror(abi.OCEAN_E_UNSUPPORTED)
+
+
+def test_argument_checking_without_device(abi):
+    L = abi.lib()
+    h = C.c_void_p()
+    assert L.ocean_create(None, 512, 1, 0) == abi.OCEAN_E_INVALID
+    assert L.ocean_create(C.byref(h), 500, 1, 0) == abi.OCEAN_E_INVALID          # not a power of two
+    assert L.ocean_create(C.byref(h), 8, 1, 0) == abi.OCEAN_E_UNSUPPORTED
+    assert L.ocean_create(C.byref(h), 8192, 1, 0) == abi.OCEAN_E_UNSUPPORTED
+    assert L.ocean_create(C.byref(h), 512, 0, 0) == abi.OCEAN_E_INVALID
+    assert L.ocean_compute_waves(None, 0.0, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_prepare(None, 0, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_tile_size(None) == 0
+    L.ocean_destroy(None)
+
+
+def test_no_cpu_fallback_when_no_gpu(abi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = abi.lib()
+    h = C.c_void_p()
+    assert L.ocean_create(C.byref(h), 512, 1, 0) == abi.OCEAN_E_NO_DEVICE
+    assert not h.value
+    import watersurfacerendering_amd as W
+    with pytest.raises(W.OceanError):
+        W.WSTessendorf(64)
+
+
+def test_product_path_never_imports_oracle():
+    """The package must not reference oracle/ (a product path through the oracle voids parity)."""
+    pkg = os.path.join(ROOT, "watersurfacerendering_amd")
+    bad = re.compile(r"(^\s*(import|from)\s+oracle\b|libocean_oracle|ocean_oracle|oracle_[a-z0-9_]+\s*\()", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                assert not bad.search(open(os.path.join(dirpath, f)).read()), (dirpath, f)
+    for f in ("ocean.h", "WSTessendorf.hpp"):
+        assert not bad.search(open(os.path.join(ROOT, "include", f)).read())
+    code = "import sys; import watersurfacerendering_amd; assert not any(m.startswith('oracle') for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+REFERENCE_METHODS = [  # /root/reference/src/scene/WSTessendorf.h:58-122
+    "Prepare", "ComputeWaves", "GetTileSize", "GetTileLength", "GetWindDir", "GetWindSpeed", "GetAnimationPeriod",
+    "GetPhillipsConst", "GetDamping", "GetDisplacementLambda", "GetMinHeight", "GetMaxHeight",
+    "GetDisplacementCount", "GetDisplacements", "GetNormalCount", "GetNormals", "SetTileSize", "SetTileLength",
+    "SetWindDirection", "SetWindSpeed", "SetAnimationPeriod", "SetPhillipsConst", "SetLambda", "SetDamping",
+]
+
+
+def test_python_mirror_has_reference_surface():
+    import watersurfacerendering_amd as W
+    for m in REFERENCE_METHODS:
+        assert callable(getattr(W.WSTessendorf, m)), m
+    assert W.WSTessendorf.s_kDefaultTileSize == 512 and W.WSTessendorf.s_kDefaultTileLength == 1000.0
+
+
+def test_cpp_adaptor_has_reference_surface_and_links(abi, tmp_path):
+    hdr = open(os.path.join(ROOT, "include", "WSTessendorf.hpp")).read()
+    for m in REFERENCE_METHODS:
+        assert re.search(r"\b%s\s*\(" % m, hdr), m
+    exe = tmp_path / "adaptor_demo"
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "adaptor_demo.cpp"), "-o", str(exe),
+           "-L", os.path.dirname(abi.LIB_PATH), "-locean_hip", "-Wl,-rpath," + os.path.dirname(abi.LIB_PATH),
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe), "64"], capture_output=True, text=True)
+        assert r.returncode == 3 and "no usable HIP device" in r.stderr   # loud failure, no fallback

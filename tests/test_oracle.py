@@ -1,0 +1,167 @@
+"""CPU tests of the oracle (test infrastructure): pins its DFT to the
+mathematical definition, its front end to an independent numpy restatement of
+the same reference lines, and checks the committed golden fixtures.
+
+PARITY UNPINNED vs the reference itself: it has no tests/vectors and cannot be
+built here (FFTW 3.3.10 + glm absent); see oracle/ocean_oracle.c header."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def naive_backward_dft2(x):
+    """B[X](p,q) = sum_{m,n} X(m,n) exp(+2 pi i (p m + q n)/N), float64, O(N^4)."""
+    n = x.shape[0]
+    w = np.exp(2j * np.pi * np.outer(np.arange(n), np.arange(n)) / n)
+    return w @ x @ w.T
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_fft_matches_naive_dft(n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    ref = naive_backward_dft2(x)
+    d = np.ascontiguousarray(np.stack([x.real, x.imag], -1), dtype=np.float64)
+    assert O.lib().oracle_fft2d_f64(n, d.ctypes.data_as(C.c_void_p)) == 0
+    got = d[..., 0] + 1j * d[..., 1]
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    f = np.ascontiguousarray(np.stack([x.real, x.imag], -1), dtype=np.float32)
+    assert O.lib().oracle_fft2d_f32(n, f.ctypes.data_as(C.c_void_p)) == 0
+    got32 = f[..., 0] + 1j * f[..., 1]
+    assert np.abs(got32 - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [64, 256, 1024])
+def test_fft_matches_pocketfft(n):
+    import scipy.fft as sfft
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    ref = sfft.ifft2(x, norm="forward")          # unnormalised backward transform (FFTW_BACKWARD)
+    d = np.ascontiguousarray(np.stack([x.real, x.imag], -1), dtype=np.float64)
+    O.lib().oracle_fft2d_f64(n, d.ctypes.data_as(C.c_void_p))
+    assert np.abs(d[..., 0] + 1j * d[..., 1] - ref).max() <= 1e-12 * np.abs(ref).max()
+    f = np.ascontiguousarray(np.stack([x.real, x.imag], -1), dtype=np.float32)
+    O.lib().oracle_fft2d_f32(n, f.ctypes.data_as(C.c_void_p))
+    assert np.abs(f[..., 0] + 1j * f[..., 1] - ref).max() <= 3e-6 * np.abs(ref).max()
+
+
+def test_fft_rejects_non_pow2():
+    d = np.zeros((12, 12, 2))
+    assert O.lib().oracle_fft2d_f64(12, d.ctypes.data_as(C.c_void_p)) != 0
+
+
+def test_gauss_rng_c_equals_numpy_and_is_standard_normal():
+    a = O.gauss_xi(77, 32)
+    b = O.gauss_xi_numpy(77, 32)
+    assert np.array_equal(a, b)
+    big = O.gauss_xi_numpy(5, 256)
+    assert abs(big.mean()) < 0.01 and abs(big.std() - 1.0) < 0.01
+    assert abs(np.mean(big[..., 0] * big[..., 1])) < 0.01
+    assert not np.array_equal(O.gauss_xi_numpy(5, 16), O.gauss_xi_numpy(6, 16))
+
+
+ALT = dict(length=250.0, wind=(1.0, 0.0), wind_speed=10.0, lam=-2.0)
+
+
+@pytest.mark.parametrize("n", [16, 64, 128])
+@pytest.mark.parametrize("alt", [False, True])
+def test_oracle_matches_independent_numpy_restatement(n, alt):
+    kw = dict(ALT) if alt else {}
+    xi = O.gauss_xi_numpy(11 + n, n)
+    length = kw.pop("length", 1000.0)
+    o = O.Oracle(n, length, **kw)
+    o.prepare(xi=xi)
+    prep = O.numpy_prepare(n, xi, length=length, **{k: v for k, v in kw.items() if k != "lam"})
+    assert np.array_equal(o.omega, prep["omega"])
+    assert np.array_equal(o.kvec[..., 0], prep["kx"]) and np.array_equal(o.kvec[..., 1], prep["kz"])
+    assert np.array_equal(o.kunit[..., 0], prep["ux"])
+    h0 = o.h0[..., 0] + 1j * o.h0[..., 1]
+    assert np.abs(h0 - prep["h0"]).max() <= 5e-7 * np.abs(prep["h0"]).max()   # expf: glibc vs numpy
+    # conj(h0(-k)) term of the reference equals conj(h0(k)) exactly
+    assert np.array_equal(o.h0_conj[..., 0], o.h0[..., 0])
+    assert np.array_equal(o.h0_conj[..., 1], -o.h0[..., 1])
+    lam = kw.get("lam", -1.0)
+    for t in (0.0, 1.5, 1000.0):
+        amp, d, q = o.compute_waves(t, fft=O.FFT_F64)
+        amp_n, d_n, q_n, mn, mx = O.numpy_compute_waves(prep, t, lam=lam)
+        assert abs(amp - amp_n) <= 1e-6 * amp_n
+        for c in range(4):
+            assert np.abs(d[..., c] - d_n[..., c]).max() <= 1e-6 * max(np.abs(d_n[..., c]).max(), 1e-30)
+            assert np.abs(q[..., c] - q_n[..., c]).max() <= 1e-6 * max(np.abs(q_n[..., c]).max(), 1e-30)
+        # the float-FFT "reference shape" stays within the fp32 floor of the f64 one
+        amp32, d32, q32 = o.compute_waves(t, fft=O.FFT_F32)
+        for c in range(3):
+            assert np.abs(d32[..., c] - d[..., c]).max() <= 2e-6 * np.abs(d[..., c]).max()
+
+
+def test_animated_height_spectrum_is_real_and_minmax_quirk():
+    """h~ is exactly real; with a zero spectrum the reported max is
+    FLT_MIN, not 0 (WSTessendorf.cpp:289-290) and A = FLT_MIN."""
+    n = 16
+    o = O.Oracle(n, phillips_a=0.0)
+    o.prepare(seed=3)
+    amp, d, q = o.compute_waves(2.0, fft=O.FFT_F32)
+    tiny = float(np.finfo(np.float32).tiny)
+    assert o.max_height == pytest.approx(tiny, rel=0, abs=0)
+    assert amp == pytest.approx(tiny, rel=0, abs=0)
+    assert np.all(d[..., 1] == 0.0) and np.all(d[..., 3] == 1.0)
+
+
+def test_modes_height1_and_choppy5():
+    n = 32
+    xi = O.gauss_xi_numpy(2, n)
+    o = O.Oracle(n)
+    o.prepare(xi=xi)
+    a7, d7, q7 = o.compute_waves(1.0, mode=O.MODE_FULL7, fft=O.FFT_F32)
+    a5, d5, q5 = o.compute_waves(1.0, mode=O.MODE_CHOPPY5, fft=O.FFT_F32)
+    a1, d1, q1 = o.compute_waves(1.0, mode=O.MODE_HEIGHT1, fft=O.FFT_F32)
+    assert a7 == a5 == a1
+    assert np.array_equal(d7, d5) and np.array_equal(q7[..., :2], q5[..., :2]) and np.all(q5[..., 2:] == 0)
+    assert np.array_equal(d1[..., 1], d7[..., 1]) and np.all(d1[..., 0] == 0) and np.all(q1 == 0)
+
+
+def test_lambda_takes_effect_without_prepare():
+    n = 16
+    o = O.Oracle(n)
+    o.prepare(seed=1)
+    _, d1, q1 = o.compute_waves(0.5, fft=O.FFT_F32)
+    o.set_lambda(-2.0)
+    _, d2, q2 = o.compute_waves(0.5, fft=O.FFT_F32)
+    assert np.allclose(d2[..., 0], 2 * d1[..., 0], rtol=1e-6) and np.array_equal(q1, q2)
+    assert np.array_equal(d1[..., 1], d2[..., 1])
+
+
+def test_spatial_mean_is_zero():
+    """DC amplitude is zero (k = 0 branch, .cpp:138-143) => every field sums to ~0 over the tile."""
+    n = 64
+    o = O.Oracle(n)
+    o.prepare(seed=9)
+    _, d, q = o.compute_waves(3.0, fft=O.FFT_F64)
+    for a in (d[..., 0], d[..., 1], d[..., 2], q[..., 0], q[..., 1]):
+        assert abs(a.mean()) <= 1e-6 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ocean_n*.npz"))))
+def test_golden_fixtures(path):
+    g = np.load(path)
+    n = int(g["n"])
+    o = O.Oracle(n, float(g["length"]), wind=tuple(g["wind"]), wind_speed=float(g["wind_speed"]),
+                 lam=float(g["lam"]))
+    o.prepare(xi=g["xi"])
+    assert np.array_equal(g["xi"], O.gauss_xi_numpy(int(g["seed"]), n))
+    assert np.array_equal(o.omega, g["omega"])
+    assert np.abs(o.h0 - g["h0"]).max() <= 1e-6 * np.abs(g["h0"]).max()
+    for i, t in enumerate(g["times"]):
+        amp, d, q = o.compute_waves(float(t), fft=O.FFT_F64)
+        assert abs(amp - float(g[f"amp{i}"])) <= 1e-6 * amp
+        assert abs(o.min_height - float(g[f"min{i}"])) <= 1e-6 * amp
+        for c in range(4):
+            assert np.abs(d[..., c] - g[f"disp{i}"][..., c]).max() <= 2e-6 * max(np.abs(d[..., c]).max(), 1e-30)
+            assert np.abs(q[..., c] - g[f"nrm{i}"][..., c]).max() <= 2e-6 * max(np.abs(q[..., c]).max(), 1e-30)

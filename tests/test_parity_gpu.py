@@ -93,3 +93,205 @@ def test_device_init_matches_oracle(n):
     assert np.array_equal(om, o.omega), float(np.abs(om - o.omega).max())
     assert np.abs(h0 - o.h0).max() <= 2e-6 * np.abs(o.h0).max()
     b.close()
+
+
+# ---------------------------------------------------------------------------
+# committed golden fixtures (inputs + expected outputs; tests/golden/make_golden.py)
+import glob
+import os
+import subprocess
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ocean_n*.npz"))))
+def test_golden_fixtures_on_gpu(path):
+    g = np.load(path)
+    n = int(g["n"])
+    b = make_gpu(n, g["xi"][None], length=float(g["length"]), wind=tuple(map(float, g["wind"])),
+                 wind_speed=float(g["wind_speed"]), lam=float(g["lam"]))
+    h0, om = b.read_spectrum(0)
+    assert np.array_equal(om, g["omega"])
+    assert np.abs(h0 - g["h0"]).max() <= 2e-6 * np.abs(g["h0"]).max()
+    for i, t in enumerate(g["times"]):
+        amp = float(b.compute_waves(float(t))[0])
+        d, q = b.read_maps()
+        assert abs(amp - float(g[f"amp{i}"])) <= TOL_AMP * amp * 2
+        assert max(chan_err(d[0], g[f"disp{i}"])) <= TOL
+        assert max(chan_err(q[0], g[f"nrm{i}"])) <= TOL
+    b.close()
+
+
+# ---------------------------------------------------------------------------
+# full BASELINE sizes: direct oracle comparison + size-independent properties
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_full_size_against_oracle_and_properties(n):
+    from oracle import oracle as O
+    seed = 0x5EED0000
+    b = make_gpu(n, None, seed=seed)
+    xi = b.read_xi(0)
+    h0, om = b.read_spectrum(0)
+    o = make_oracle(n, xi)
+    assert np.array_equal(om, o.omega)
+    t = 2.75
+    ed, en = check_frame(b, o, t)
+    d, q = b.read_maps()
+    d, q = d[0].astype(np.float64), q[0].astype(np.float64)
+    amp = b.heights(0)[0]
+    # (1) zero DC amplitude => every field has zero spatial mean
+    for a in (d[..., 0], d[..., 1], d[..., 2], q[..., 0], q[..., 1], q[..., 2], q[..., 3]):
+        assert abs(a.mean()) <= 2e-6 * np.abs(a).max()
+    # (2) Parseval for the height: sum h^2 = N^2 * sum |H_h|^2, H_h = (H(k) + H(-k))/2
+    wt = (om * np.float32(t)).astype(np.float32).astype(np.float64)
+    H = 2.0 * (h0[..., 0].astype(np.float64) * np.cos(wt) - h0[..., 1].astype(np.float64) * np.sin(wt))
+    Hm = np.roll(H[::-1, ::-1], (1, 1), axis=(0, 1))          # H at ((N-m)%N, (N-n)%N)
+    Hh = 0.5 * (H + Hm)
+    lhs = float(np.sum((d[..., 1] * amp) ** 2))
+    rhs = float(n * n * np.sum(Hh ** 2))
+    assert abs(lhs - rhs) <= 1e-5 * rhs
+    # (3) sampled texels against the defining DFT sum in float64 (O(N^2) each)
+    k1 = o.kvec[0, :, 0].astype(np.float64)
+    idx = np.arange(n)
+    rng = np.random.default_rng(n)
+    for p, qq in rng.integers(0, n, size=(3, 2)):
+        ph = np.exp(2j * np.pi * (p * idx[:, None] + qq * idx[None, :]) / n)
+        s = -1.0 if (p + qq) & 1 else 1.0
+        hval = s * float(np.sum(H * ph).real)
+        sxval = s * float(np.sum(1j * k1[None, :] * H * ph).real)
+        assert abs(hval / amp - d[p, qq, 1]) <= TOL * 1.0
+        assert abs(sxval - q[p, qq, 0]) <= TOL * np.abs(q[..., 0]).max()
+    b.close()
+
+
+def test_lambda_scales_displacement_only():
+    n = 256
+    b = make_gpu(n, None, seed=5)
+    b.compute_waves(1.0)
+    d1, q1 = b.read_maps()
+    b.set_lambda(-2.0)                      # SetLambda: no Prepare needed (.cpp:497-500)
+    b.compute_waves(1.0)
+    d2, q2 = b.read_maps()
+    assert np.array_equal(q1, q2) and np.array_equal(d1[..., 1], d2[..., 1])
+    assert np.allclose(d2[..., 0], 2.0 * d1[..., 0], rtol=1e-6, atol=0)
+    assert np.allclose(d2[..., 2], 2.0 * d1[..., 2], rtol=1e-6, atol=0)
+    b.close()
+
+
+def test_zero_spectrum_minmax_quirk():
+    """Reference quirk: max starts at FLT_MIN (.cpp:289-290) => A = FLT_MIN for a flat sea."""
+    b = make_gpu(32, None, seed=1, phillips_a=0.0)
+    amp = float(b.compute_waves(2.0)[0])
+    a, mn, mx = b.heights(0)
+    tiny = float(np.finfo(np.float32).tiny)
+    assert amp == tiny and mx == tiny and mn == 0.0
+    d, q = b.read_maps()
+    assert np.all(d[..., 1] == 0.0) and np.all(d[..., 3] == 1.0) and np.all(q == 0.0)
+    b.close()
+
+
+def test_batch_tiles_are_independent_and_match_single_tile_runs():
+    from oracle import oracle as O
+    n, tiles, seed = 128, 5, 700
+    b = make_gpu(n, None, seed=seed, tiles=tiles)
+    offs = np.array([0.0, 0.5, 1.0, 10.0, 100.0], np.float32)
+    b.set_time_offsets(offs)
+    amps = b.compute_waves(1.0)
+    d, q = b.read_maps()
+    for i in range(tiles):
+        xi = O.gauss_xi_numpy(seed + i, n)        # tile i uses seed + i
+        assert np.abs(b.read_xi(i) - xi).max() <= 1e-6 * np.abs(xi).max()
+        o = make_oracle(n, b.read_xi(i))
+        ao, do, no = o.compute_waves(float(np.float32(1.0) + offs[i]), fft=O.FFT_F64)
+        assert abs(float(amps[i]) - ao) <= TOL_AMP * ao
+        assert max(chan_err(d[i], do)) <= TOL and max(chan_err(q[i], no)) <= TOL
+    b.set_time_offsets(None)
+    b.close()
+
+
+def test_python_mirror_and_resize():
+    """WSTessendorf mirror: reference call order, SetTileSize + Prepare, ignored bad size."""
+    import watersurfacerendering_amd as W
+    from oracle import oracle as O
+    ws = W.WSTessendorf(64, 500.0)
+    ws.SetWindDirection((0.0, 2.0)); ws.SetWindSpeed(12.0); ws.SetDamping(0.2); ws.SetPhillipsConst(5e-7)
+    ws.SetAnimationPeriod(100.0); ws.SetLambda(-0.5)
+    ws.SetTileSize(100)                       # not a power of two: ignored (.cpp:463-467)
+    assert ws.GetTileSize() == 64
+    assert ws.GetWindDir() == pytest.approx((0.0, 1.0))
+    ws.SetTileSize(128)
+    xi = O.gauss_xi_numpy(8, 128)
+    ws.Prepare(seed=8, xi=xi[None])
+    assert ws.GetDisplacementCount() == 128 * 128 and np.all(ws.GetNormals()[..., 1] == 1.0)
+    amp = ws.ComputeWaves(4.0)
+    o = make_oracle(128, xi, length=500.0, wind=(0.0, 2.0), wind_speed=12.0, damping=0.2, phillips_a=5e-7,
+                    anim_period=100.0, lam=-0.5)
+    ao, do, no = o.compute_waves(4.0, fft=O.FFT_F64)
+    assert abs(amp - ao) <= TOL_AMP * ao
+    assert max(chan_err(ws.GetDisplacements(), do)) <= TOL and max(chan_err(ws.GetNormals(), no)) <= TOL
+    assert ws.GetMinHeight() == pytest.approx(o.min_height, rel=1e-5)
+    assert ws.GetMaxHeight() == pytest.approx(o.max_height, rel=1e-5)
+
+
+def test_errors_and_ordering():
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi
+    b = W.OceanBatch(64, 1, 0)
+    with pytest.raises(W.OceanError) as e:
+        b.compute_waves(0.0)                  # before Prepare
+    assert e.value.code == _abi.OCEAN_E_NOT_READY
+    with pytest.raises(W.OceanError):
+        W.OceanBatch(64, 1, 99)               # no such device
+    b.prepare(1)
+    b.compute_waves(0.0)
+    b.set_tile_size(32)                       # resize invalidates the prepared state
+    with pytest.raises(W.OceanError):
+        b.compute_waves(0.0)
+    b.close()
+
+
+def test_bind_output_and_async_stream_order():
+    import torch
+    import watersurfacerendering_amd as W
+    n = 256
+    b = W.OceanBatch(n, 1, 0)
+    b.prepare(3)
+    b.compute_waves(0.25)
+    d_ref, q_ref = b.read_maps()
+    maps = torch.zeros((2, n, n, 4), dtype=torch.float32, device="cuda:0")
+    b.bind_output(maps[0].data_ptr(), maps[1].data_ptr())
+    b.compute_waves_async(0.25)
+    b.synchronize()
+    got = maps.cpu().numpy()
+    assert np.array_equal(got[0], d_ref[0]) and np.array_equal(got[1], q_ref[0])   # deterministic, bit for bit
+    b.bind_output(None, None)
+    b.close()
+
+
+def test_frames_are_deterministic():
+    b = make_gpu(512, None, seed=11)
+    b.compute_waves(3.0); d1, q1 = b.read_maps()
+    b.compute_waves(9.0)
+    b.compute_waves(3.0); d2, q2 = b.read_maps()
+    assert np.array_equal(d1, d2) and np.array_equal(q1, q2)
+    b.close()
+
+
+def test_cpp_adaptor_matches_python_binding(tmp_path):
+    from watersurfacerendering_amd import _abi
+    exe = tmp_path / "adaptor_demo"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "adaptor_demo.cpp"), "-o", str(exe),
+                    "-L", os.path.dirname(_abi.LIB_PATH), "-locean_hip", "-Wl,-rpath," + os.path.dirname(_abi.LIB_PATH),
+                    "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), "128", "1.5"], capture_output=True, text=True, check=True)
+    n, amp, mn, mx, sd, sn = r.stdout.split()
+    b = make_gpu(128, None, seed=42, wind=(1.0, 0.5), wind_speed=20.0, lam=-1.5)
+    a = float(b.compute_waves(1.5)[0])
+    d, q = b.read_maps()
+    w7 = (np.arange(d[0].size) % 7 + 1).astype(np.float64)
+    w5 = ((np.arange(q[0].size) + d[0].size) % 5 + 1).astype(np.float64)
+    assert int(n) == 128 and float(amp) == pytest.approx(a, rel=1e-7)
+    assert float(sd) == pytest.approx(float(np.sum(d[0].astype(np.float64).ravel() * w7)), rel=1e-9, abs=1e-6)
+    assert float(sn) == pytest.approx(float(np.sum(q[0].astype(np.float64).ravel() * w5)), rel=1e-9, abs=1e-6)
+    b.close()
