@@ -1,0 +1,24 @@
+"""Diagnostic: per-workgroup phase stamps of k_rows (needs the -DOCEAN_STAMPS variant)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import watersurfacerendering_amd as W
+from watersurfacerendering_amd import _abi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+nst = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+b = W.OceanBatch(n, 1, 0); b.prepare(1)
+L = _abi.lib()
+L.ocean_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+for j in range(3): b.compute_waves_async(0.1 * j)
+b.synchronize()
+L.ocean_debug_stamps(b._h, 1, None, 0)
+b.compute_waves_async(1.0); b.synchronize()
+nb = n // 2
+out = np.zeros(nb * 16, dtype=np.uint64)
+L.ocean_debug_stamps(b._h, 1, out.ctypes.data_as(C.c_void_p), out.size)
+st = out.reshape(nb, 16)[:, :nst].astype(np.int64)
+t0 = st[:, 0].min()
+d = np.diff(st, axis=1)
+print("blocks", nb, "span (cycles @100MHz?) first start -> last end:", st[:, nst-1].max() - t0)
+print("phase durations median:", np.median(d, axis=0), " mean:", d.mean(axis=0))
+print("block total median", np.median(st[:, nst-1] - st[:, 0]), "start times pct:", np.percentile(st[:, 0] - t0, [0, 25, 50, 75, 100]))

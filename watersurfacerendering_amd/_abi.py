@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libocean_hip.so")
+_BUILT_LIB = os.path.join(_PKG, "libocean_hip.so")
+LIB_PATH = os.environ.get("OCEAN_HIP_LIB") or _BUILT_LIB   # env override: kernel A/B builds only
 CSRC = os.path.join(_PKG, "csrc")
 
 OCEAN_OK = 0
@@ -51,10 +52,10 @@ def build(force: bool = False) -> str:
     """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in ("ocean_api.hip", "ocean_kernels.h", "fft_engine.h", "Makefile")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    stale = (not os.path.exists(_BUILT_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_BUILT_LIB) for s in srcs)
     if force or stale:
         subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
-    return LIB_PATH
+    return _BUILT_LIB
 
 
 _lib = None

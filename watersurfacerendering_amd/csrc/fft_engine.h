@@ -123,23 +123,29 @@ __device__ __forceinline__ void apply_twiddles(c32 (&x)[R], c32 w1)
 }
 
 // ---- radix plans -------------------------------------------------------------
-template <int N> struct Plan;
-#define OCEAN_PLAN(n, a, b, c) \
-    template <> struct Plan<n> { static constexpr int r0 = a, r1 = b, r2 = c; };
-OCEAN_PLAN(16, 16, 1, 1)
-OCEAN_PLAN(32, 8, 4, 1)
-OCEAN_PLAN(64, 8, 8, 1)
-OCEAN_PLAN(128, 16, 8, 1)
-OCEAN_PLAN(256, 16, 16, 1)
-OCEAN_PLAN(512, 8, 8, 8)
-OCEAN_PLAN(1024, 16, 8, 8)
-OCEAN_PLAN(2048, 16, 16, 8)
-OCEAN_PLAN(4096, 16, 16, 16)
-#undef OCEAN_PLAN
-
-template <int N> struct LastRadix {
-    static constexpr int value = Plan<N>::r2 != 1 ? Plan<N>::r2 : (Plan<N>::r1 != 1 ? Plan<N>::r1 : Plan<N>::r0);
+template <int... Rs> struct Radices {
+    static constexpr int S = sizeof...(Rs);
+    static constexpr int r[sizeof...(Rs)] = {Rs...};
+    static constexpr int last = r[S - 1];
+    static constexpr int product()
+    {
+        int p = 1;
+        for (int i = 0; i < S; ++i) p *= r[i];
+        return p;
+    }
 };
+
+// default plan per transform length (large radices: fewest LDS exchanges)
+template <int N> struct Plan;
+template <> struct Plan<16> : Radices<16> {};
+template <> struct Plan<32> : Radices<8, 4> {};
+template <> struct Plan<64> : Radices<8, 8> {};
+template <> struct Plan<128> : Radices<16, 8> {};
+template <> struct Plan<256> : Radices<16, 16> {};
+template <> struct Plan<512> : Radices<8, 8, 8> {};
+template <> struct Plan<1024> : Radices<16, 8, 8> {};
+template <> struct Plan<2048> : Radices<16, 16, 8> {};
+template <> struct Plan<4096> : Radices<16, 16, 16> {};
 
 template <int N> constexpr int lds_padded() { return N + N / 16; }
 template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() * C; }
@@ -168,11 +174,13 @@ __device__ __forceinline__ void fft_stage(c32* lds, const c32* __restrict__ tw, 
                 if constexpr (FIRST) x[u][i] = in(j + i * (N / R), c);
                 else x[u][i] = lds[lds_index<C>(j + i * (N / R), c)];
             }
+#ifndef OCEAN_ABL_NOFFT
             if constexpr (NS > 1) {
                 const int k = j % NS;
                 apply_twiddles<R>(x[u], tw[k * (N / (NS * R))]);
             }
             Dft<R>::run(x[u]);
+#endif
         }
     }
     if constexpr (!LAST) __syncthreads();   // every reader of the old image is done
@@ -192,35 +200,33 @@ __device__ __forceinline__ void fft_stage(c32* lds, const c32* __restrict__ tw, 
     }
 }
 
-// C interleaved length-N transforms by the T threads of the workgroup.
-// `lds` needs fft_lds_elems<N, C>() float2; `tw[k] = exp(+2 pi i k / N)`.
-// The call may start while other waves still read `lds` from a previous call:
-// the first LDS write is preceded by a barrier.
-template <int N, int C, int T, class In, class Out>
+template <int N, int C, int T, class P, int STAGE, int NS, class In, class Out>
+__device__ __forceinline__ void run_stages(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
+{
+    constexpr int R = P::r[STAGE];
+    constexpr bool FIRST = STAGE == 0, LAST = STAGE == P::S - 1;
+    fft_stage<N, R, NS, C, T, FIRST, LAST>(lds, tw, tid, in, out);
+    if constexpr (!LAST) {
+        __syncthreads();
+        run_stages<N, C, T, P, STAGE + 1, NS * R>(lds, tw, tid, in, out);
+    }
+}
+
+// C interleaved length-N transforms by the T threads of the workgroup, radix
+// plan P (product of radices = N).  `lds` needs fft_lds_elems<N, C>() float2;
+// `tw[k] = exp(+2 pi i k / N)`.  The call may start while other waves still
+// read `lds` from a previous call: the first LDS write is preceded by a barrier.
+template <int N, int C, int T, class P = Plan<N>, class In, class Out>
 __device__ __forceinline__ void batch_fft(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
 {
-    constexpr int R0 = Plan<N>::r0, R1 = Plan<N>::r1, R2 = Plan<N>::r2;
-    auto none_in = [](int, int) { return make_float2(0.f, 0.f); };
-    auto none_out = [](int, int, c32, int, int) {};
-    if constexpr (R1 == 1) {
-        fft_stage<N, R0, 1, C, T, true, true>(lds, tw, tid, in, out);
-    } else if constexpr (R2 == 1) {
-        fft_stage<N, R0, 1, C, T, true, false>(lds, tw, tid, in, none_out);
-        __syncthreads();
-        fft_stage<N, R1, R0, C, T, false, true>(lds, tw, tid, none_in, out);
-    } else {
-        fft_stage<N, R0, 1, C, T, true, false>(lds, tw, tid, in, none_out);
-        __syncthreads();
-        fft_stage<N, R1, R0, C, T, false, false>(lds, tw, tid, none_in, none_out);
-        __syncthreads();
-        fft_stage<N, R2, R0 * R1, C, T, false, true>(lds, tw, tid, none_in, out);
-    }
+    static_assert(P::product() == N, "radix plan does not match the transform length");
+    run_stages<N, C, T, P, 0, 1>(lds, tw, tid, in, out);
 }
 
 // Mapping of the LAST stage: work item w = tid + u*T owns outputs
 // idx = j + i*(N/RL), column c, with j = w / C, c = w % C (k == j there).
-template <int N, int C, int T> struct LastStage {
-    static constexpr int RL = LastRadix<N>::value;
+template <int N, int C, int T, class P = Plan<N>> struct LastStage {
+    static constexpr int RL = P::last;
     static constexpr int ITEMS = (N / RL) * C;
     static constexpr int IT = (ITEMS + T - 1) / T;
     static constexpr bool GUARD = (ITEMS % T) != 0;

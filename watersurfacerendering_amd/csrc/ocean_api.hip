@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -55,6 +56,7 @@ struct ocean_ctx {
     TileParams* tparams = nullptr;
     float2* xi = nullptr;          // injected or generated draws (kept for read-back)
     unsigned* h_minmax = nullptr;  // pinned
+    unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t ev[8] = {};
 };
 
@@ -299,22 +301,27 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int which /* bi
     constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, G::CM>();
     static bool attr_done = false;
     if (!attr_done) {
-        if ((e = allow_lds(k_rows<N, G::RP, G::T_ROWS>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_cols_height<N, G::CP, G::T_H>, lds_h)) != hipSuccess) return e;
-        if ((e = allow_lds(k_cols_maps<N, G::CM, G::T_M>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rows<N, G::RP, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_cols_height<N, G::CP, G::T_H, typename G::PH>, lds_h)) != hipSuccess) return e;
+        if ((e = allow_lds(k_cols_maps<N, G::CM, G::T_M, typename G::PM>, lds_m)) != hipSuccess) return e;
         attr_done = true;
     }
     if (marks) (void)hipEventRecord(marks[0], c->stream);
-    if (which & 1)
-        hipLaunchKernelGGL((k_rows<N, G::RP, G::T_ROWS>), dim3(N / 2 / G::RP, tiles), dim3(G::T_ROWS), lds_rows,
+    if (which & 1) {
+        unsigned gx = N / 2 / G::RP;
+#ifdef OCEAN_STAMPS
+        if (const char* e = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(e);   // diagnostic: partial grid
+#endif
+        hipLaunchKernelGGL((k_rows<N, G::RP, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows,
                            c->stream, a);
+    }
     if (marks) (void)hipEventRecord(marks[1], c->stream);
     if (which & 2)
-        hipLaunchKernelGGL((k_cols_height<N, G::CP, G::T_H>), dim3(N / (2 * G::CP), tiles), dim3(G::T_H), lds_h,
+        hipLaunchKernelGGL((k_cols_height<N, G::CP, G::T_H, typename G::PH>), dim3(N / (2 * G::CP), tiles), dim3(G::T_H), lds_h,
                            c->stream, a);
     if (marks) (void)hipEventRecord(marks[2], c->stream);
     if (which & 4)
-        hipLaunchKernelGGL((k_cols_maps<N, G::CM, G::T_M>), dim3(N / G::CM, tiles, 2), dim3(G::T_M), lds_m,
+        hipLaunchKernelGGL((k_cols_maps<N, G::CM, G::T_M, typename G::PM>), dim3(N / G::CM, tiles, 2), dim3(G::T_M), lds_m,
                            c->stream, a);
     if (marks) (void)hipEventRecord(marks[3], c->stream);
     return hipGetLastError();
@@ -332,6 +339,7 @@ static int enqueue_frame(ocean_ctx* c, float t, int which, hipEvent_t* marks)
     a.toff = c->use_toff ? c->toff : nullptr;
     a.lambda = c->lambda;
     a.t = t;
+    a.stamps = c->stamps;
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
         case 16: e = launch_frame<16>(c, a, which, marks); break;
@@ -518,6 +526,22 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     }
     return OCEAN_OK;
 }
+
+#ifdef OCEAN_STAMPS
+// diagnostic build only: per-workgroup clock stamps of the last frame
+int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, size_t count)
+{
+    if (!c) return OCEAN_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (enable && !c->stamps) {
+        HIP_TRY(hipMalloc(&c->stamps, (size_t)1 << 24));
+        HIP_TRY(hipMemset(c->stamps, 0, (size_t)1 << 24));
+    }
+    if (host_out) HIP_TRY(hipMemcpy(host_out, c->stamps, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+#endif
 
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {

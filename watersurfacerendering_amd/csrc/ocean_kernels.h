@@ -50,7 +50,14 @@ struct FrameArgs {
     const float* toff;       // [tiles] or null
     const float* lambda;     // [tiles]
     float t;
+    unsigned long long* stamps;   // diagnostic builds only (-DOCEAN_STAMPS), else null
 };
+
+#ifdef OCEAN_STAMPS
+#define OCEAN_STAMP(k) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + (k)] = clock64(); } while (0)
+#else
+#define OCEAN_STAMP(k) do {} while (0)
+#endif
 
 // ---- float <-> order-preserving unsigned key (for atomicMin/atomicMax) -----
 __host__ __device__ inline unsigned float_key(float f)
@@ -158,7 +165,11 @@ __device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
 #pragma clang fp contract(off)
     const float wt = w * t;
     float s, c;
+#ifdef OCEAN_ABL_SINCOS
+    s = wt * 1e-4f; c = 1.0f - s;
+#else
     sincosf(wt, &s, &c);
+#endif
     const float re = h0r * c - h0i * s;
     return re + re;
 }
@@ -167,15 +178,17 @@ __device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
 // k_rows: RP row pairs (r, N-r) per workgroup (pair 0 = the two self-mirrored
 // rows 0 and N/2).  Slot s = 2*rr + side holds row r (side 0) or its mirror.
 // ============================================================================
-template <int N, int RP, int T>
-__global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
+#ifndef OCEAN_ROWS_MINW
+#define OCEAN_ROWS_MINW 1
+#endif
+template <int N, int RP, int T, class P = Plan<N>>
+__global__ void __launch_bounds__(T, OCEAN_ROWS_MINW) k_rows(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int C = 2 * RP;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     constexpr int HS = N + 16;   // row stride of hs: +16 banks between the two rows of a pair
     float* hs = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());   // [C][HS]
-    float* k1 = hs + C * HS;                                              // [N]
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
@@ -184,31 +197,58 @@ __global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
     const float2* __restrict__ h0 = a.h0 + tile * n2;
     const float* __restrict__ om = a.omega + tile * n2;
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
+    const float* __restrict__ k1 = a.k1d + (size_t)tile * N;              // [N], L1-resident table
 
     auto row_of = [&](int s) {
         const int r = r0 + (s >> 1);
         return (s & 1) ? (r == 0 ? N / 2 : N - r) : r;
     };
 
+    OCEAN_STAMP(0);
     // -- phase 1: animate both rows of every pair into LDS -------------------
-    for (int e = tid; e < C * (N / 2); e += T) {
-        const int s = e / (N / 2);
-        const int n = (e % (N / 2)) * 2;
-        const size_t g = (size_t)row_of(s) * N + n;
-        const float4 h = *reinterpret_cast<const float4*>(h0 + g);
-        const float2 w = *reinterpret_cast<const float2*>(om + g);
-        float2 v;
-        v.x = animate(h.x, h.y, w.x, t);
-        v.y = animate(h.z, h.w, w.y, t);
-        *reinterpret_cast<float2*>(hs + s * HS + n) = v;
+    // all global loads of the workgroup's input are issued before the first
+    // sincos: one HBM round trip per workgroup instead of one per iteration
+    {
+        constexpr int P1 = (C * (N / 2)) / T;
+        static_assert((C * (N / 2)) % T == 0, "phase-1 tiling");
+        constexpr int PB = P1 > 4 ? 4 : P1;          // loads in flight per thread per batch (6 VGPRs each)
+        static_assert(P1 % PB == 0, "phase-1 batches");
+#pragma unroll 1
+        for (int ub = 0; ub < P1; ub += PB) {
+            float4 hv[PB];
+            float2 wv[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = tid + (ub + u) * T;
+                const int s = e / (N / 2);
+                const int n = (e % (N / 2)) * 2;
+                const size_t g = (size_t)row_of(s) * N + n;
+#ifdef OCEAN_ABL_NOLOAD
+                hv[u] = make_float4(1.f + g, 2.f, 3.f, 4.f); wv[u] = make_float2(0.5f, 0.25f);
+#else
+                hv[u] = *reinterpret_cast<const float4*>(h0 + g);
+                wv[u] = *reinterpret_cast<const float2*>(om + g);
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = tid + (ub + u) * T;
+                const int s = e / (N / 2);
+                const int n = (e % (N / 2)) * 2;
+                float2 v;
+                v.x = animate(hv[u].x, hv[u].y, wv[u].x, t);
+                v.y = animate(hv[u].z, hv[u].w, wv[u].y, t);
+                *reinterpret_cast<float2*>(hs + s * HS + n) = v;
+            }
+        }
     }
-    for (int n = tid; n < N; n += T) k1[n] = a.k1d[(size_t)tile * N + n];
     if (blockIdx.x == 0 && tid == 0) {
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
         a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
     }
     __syncthreads();
+    OCEAN_STAMP(1);
 
     // -- phase 2: three packed pairs, C row transforms each ------------------
     // per element: a = h~(k), b = h~(-k);  -k <-> ((N-m)%N, (N-n)%N), and
@@ -221,6 +261,9 @@ __global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
             const int ms = (r == 0) ? s : (s ^ 1);
             const float av = hs[s * HS + n];
             const float bv = hs[ms * HS + ((N - n) & (N - 1))];
+#ifdef OCEAN_ABL_NOIN
+            return make_float2(av, bv);
+#endif
             const float kxa = k1[n];
             const float kza = k1[row_of(s)];
             const float kxb = (n == 0) ? kxa : -kxa;
@@ -247,8 +290,13 @@ __global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
             const float f = 0.5f * (kza * uza * av + kzb * uzb * bv);
             return make_float2(e, f);
         };
+#ifdef OCEAN_ABL_NOSTORE
+        auto out = [&](int q, int s, c32 v, int, int) { asm volatile("" ::"v"(v.x), "v"(v.y)); if (q < 0) zg[q] = v; };
+#else
         auto out = [&](int q, int s, c32 v, int, int) { zg[(size_t)row_of(s) * N + q] = v; };
-        batch_fft<N, C, T>(fbuf, a.tw, tid, in, out);
+#endif
+        batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
+        OCEAN_STAMP(2 + g);
     }
 
     // -- height alone: one transform per pair, rows 0..N/2-1 ------------------
@@ -262,13 +310,14 @@ __global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
             return make_float2(0.5f * (hs[(2 * rr) * HS + n] + hs[(2 * rr + 1) * HS + nm]), 0.0f);
         };
         auto out = [&](int q, int rr, c32 v, int, int) { zh[(size_t)(r0 + rr) * N + q] = v; };
-        batch_fft<N, RP, T>(fbuf, a.tw, tid, in, out);
+        batch_fft<N, RP, T, P>(fbuf, a.tw, tid, in, out);
+        OCEAN_STAMP(5);
     }
 }
 
 template <int N, int RP> constexpr size_t rows_lds_bytes()
 {
-    return sizeof(c32) * fft_lds_elems<N, 2 * RP>() + sizeof(float) * (2 * RP * (N + 16) + N);
+    return sizeof(c32) * fft_lds_elems<N, 2 * RP>() + sizeof(float) * (2 * RP * (N + 16));
 }
 
 // XCD-aware panel order: workgroups are dealt round-robin over the 8 XCDs, so
@@ -285,7 +334,7 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
 // complex transform.  Column input Y_q(m) = Zh(m, q) for m < N/2 and its
 // conjugate mirror above; rows 0 and N/2 (real) are packed in Zh row 0.
 // ============================================================================
-template <int N, int CP, int T>
+template <int N, int CP, int T, class P = Plan<N>>
 __global__ void __launch_bounds__(T) k_cols_height(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -315,7 +364,7 @@ __global__ void __launch_bounds__(T) k_cols_height(const FrameArgs a)
         vmax = fmaxf(vmax, fmaxf(h0v, h1v));
         *reinterpret_cast<float2*>(hraw + (size_t)p * N + q) = make_float2(h0v, h1v);
     };
-    batch_fft<N, CP, T>(fbuf, a.tw, tid, in, out);
+    batch_fft<N, CP, T, P>(fbuf, a.tw, tid, in, out);
 
     // workgroup reduction -> one atomic pair (.cpp:391-392, 407-411)
 #pragma unroll
@@ -336,12 +385,12 @@ __global__ void __launch_bounds__(T) k_cols_height(const FrameArgs a)
 // k_cols_maps: C columns per workgroup.  blockIdx.z = 0: displacement map
 // (pair 0 + height), 1: normal map (pairs 1 and 2).
 // ============================================================================
-template <int N, int C, int T>
+template <int N, int C, int T, class P = Plan<N>>
 __global__ void __launch_bounds__(T) k_cols_maps(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* fbuf = reinterpret_cast<c32*>(smem);
-    using LS = LastStage<N, C, T>;
+    using LS = LastStage<N, C, T, P>;
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
     const int q0 = xcd_swizzle(blockIdx.x, gridDim.x) * C;
@@ -375,7 +424,7 @@ __global__ void __launch_bounds__(T) k_cols_maps(const FrameArgs a)
             // (sign*lambda)*Re Dx, h/A, (sign*lambda)*Re Dz, 1   (.cpp:394-403)
             disp[(size_t)p * N + q] = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
         };
-        batch_fft<N, C, T>(fbuf, a.tw, tid, in, out);
+        batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
     } else {
         float4* __restrict__ nrm = a.nrm + tile * n2;
         c32 held[LS::IT][LS::RL];
@@ -383,7 +432,7 @@ __global__ void __launch_bounds__(T) k_cols_maps(const FrameArgs a)
             const float2* __restrict__ z1 = zt + n2;
             auto in = [&](int m, int c) -> c32 { return z1[(size_t)m * N + q0 + c]; };
             auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
-            batch_fft<N, C, T>(fbuf, a.tw, tid, in, out);
+            batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
         }
         {
             const float2* __restrict__ z2 = zt + 2 * n2;
@@ -394,28 +443,35 @@ __global__ void __launch_bounds__(T) k_cols_maps(const FrameArgs a)
                 // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
                 nrm[(size_t)p * N + q] = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
             };
-            batch_fft<N, C, T>(fbuf, a.tw, tid, in, out);
+            batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
         }
     }
 }
 
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
-#define OCEAN_GEO(n, rp, tr, cp, th, cm, tm)                                                   \
+#define OCEAN_GEO(n, rp, tr, pr, cp, th, ph, cm, tm, pm)                                       \
     template <> struct Geo<n> {                                                                \
         static constexpr int RP = rp, T_ROWS = tr;      /* row pairs per workgroup, threads */ \
         static constexpr int CP = cp, T_H = th;         /* column pairs (height), threads   */ \
         static constexpr int CM = cm, T_M = tm;         /* columns (maps), threads          */ \
+        using PR = pr; using PH = ph; using PM = pm;    /* radix plans                      */ \
     };
-OCEAN_GEO(16, 8, 64, 8, 64, 16, 64)
-OCEAN_GEO(32, 8, 64, 8, 64, 16, 64)
-OCEAN_GEO(64, 4, 64, 8, 64, 16, 128)
-OCEAN_GEO(128, 4, 64, 8, 64, 16, 128)
-OCEAN_GEO(256, 4, 128, 8, 128, 16, 256)
-OCEAN_GEO(512, 1, 128, 2, 128, 8, 256)
-OCEAN_GEO(1024, 1, 128, 4, 256, 8, 512)
-OCEAN_GEO(2048, 1, 256, 4, 512, 8, 1024)
-OCEAN_GEO(4096, 1, 512, 2, 512, 4, 1024)
+#define OCEAN_R(...) Radices<__VA_ARGS__>
+OCEAN_GEO(16, 8, 64, Plan<16>, 8, 64, Plan<16>, 16, 64, Plan<16>)
+OCEAN_GEO(32, 8, 64, Plan<32>, 8, 64, Plan<32>, 16, 64, Plan<32>)
+OCEAN_GEO(64, 4, 64, Plan<64>, 8, 64, Plan<64>, 16, 128, Plan<64>)
+OCEAN_GEO(128, 4, 64, Plan<128>, 8, 64, Plan<128>, 16, 128, Plan<128>)
+OCEAN_GEO(256, 4, 128, Plan<256>, 8, 128, Plan<256>, 16, 256, Plan<256>)
+OCEAN_GEO(512, 1, 128, Plan<512>, 2, 128, Plan<512>, 8, 256, Plan<512>)
+OCEAN_GEO(1024, 1, 128, Plan<1024>, 4, 256, Plan<1024>, 8, 512, Plan<1024>)
+#ifdef OCEAN_ROWS_R8
+OCEAN_GEO(2048, 1, 512, OCEAN_R(8, 8, 8, 4), 4, 512, Plan<2048>, 8, 1024, Plan<2048>)
+#else
+OCEAN_GEO(2048, 1, 256, Plan<2048>, 4, 512, Plan<2048>, 8, 1024, Plan<2048>)
+#endif
+OCEAN_GEO(4096, 1, 512, Plan<4096>, 2, 512, Plan<4096>, 4, 1024, Plan<4096>)
+#undef OCEAN_R
 #undef OCEAN_GEO
 
 }  // namespace ocean
