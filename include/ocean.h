@@ -143,8 +143,8 @@ int ocean_read_xi(ocean_t* ctx, uint32_t tile, float* xi);
 
 /* Times `frames` back-to-back frames (t = t0 + j*dt) with HIP events on the
  * context's stream after `warmup` untimed ones.  ms_total = whole timed region;
- * ms_kernel[3] = mean duration per launch of {row pass, height column pass,
- * map column pass}, measured with events bracketing each launch on a second,
+ * ms_kernel[3] = mean duration per launch of {row pass, column pass B (height +
+ * normal map), column pass C (displacement map)}, measured with events bracketing each launch on a second,
  * separately timed run of the same frames.  Any output pointer may be NULL.     */
 int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
                       float* ms_total, float* ms_kernel /* [3] */);

@@ -138,6 +138,27 @@ def test_lambda_takes_effect_without_prepare():
     assert np.array_equal(d1[..., 1], d2[..., 1])
 
 
+def test_reference_output_point_symmetry():
+    """h~(k) is real for every k (.cpp:131-135, .h:265-275) => every output field is even or odd
+    under (p,q) -> (-p,-q) mod N: height and dD/dx even, displacements and slopes odd.
+    The HIP pipeline computes one half and mirrors the other (ocean_kernels.h)."""
+    n = 64
+    o = O.Oracle(n, **ALT_SYM)
+    o.prepare(seed=5)
+    for fft in (O.FFT_F64, O.FFT_F32):
+        _, d, q = o.compute_waves(3.3, fft=fft)
+
+        def mir(a):
+            return np.roll(a[::-1, ::-1], (1, 1), axis=(0, 1))
+        tol = 0.0 if fft == O.FFT_F64 else 2e-6
+        for a, eps in ((d[..., 0], -1), (d[..., 1], 1), (d[..., 2], -1), (q[..., 0], -1), (q[..., 1], -1),
+                       (q[..., 2], 1), (q[..., 3], 1)):
+            assert np.abs(a - eps * mir(a)).max() <= tol * np.abs(a).max() + 1e-7 * np.abs(a).max()
+
+
+ALT_SYM = dict(wind=(0.3, -1.0), wind_speed=17.0)
+
+
 def test_spatial_mean_is_zero():
     """DC amplitude is zero (k = 0 branch, .cpp:138-143) => every field sums to ~0 over the tile."""
     n = 64

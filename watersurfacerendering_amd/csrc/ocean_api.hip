@@ -81,9 +81,14 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMalloc(&c->omega, t * n2 * sizeof(float)));
     HIP_TRY(hipMalloc(&c->k1d, t * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->tw, n * sizeof(float2)));
-    HIP_TRY(hipMalloc(&c->z, t * 3 * n2 * sizeof(float2)));
-    HIP_TRY(hipMalloc(&c->zh, t * (n / 2) * n * sizeof(float2)));
-    HIP_TRY(hipMalloc(&c->hraw, t * n2 * sizeof(float)));
+    // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
+    const size_t nu = n / 2 + 1, nup = n / 2 + 8;
+    HIP_TRY(hipMalloc(&c->z, t * 3 * nu * 2 * nup * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->zh, t * nu * nup * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->hraw, t * nup * n * sizeof(float)));
+    HIP_TRY(hipMemset(c->z, 0, t * 3 * nu * 2 * nup * sizeof(float2)));
+    HIP_TRY(hipMemset(c->zh, 0, t * nu * nup * sizeof(float2)));
+    HIP_TRY(hipMemset(c->hraw, 0, t * nup * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->minmax, t * 2 * sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->disp, t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->nrm, t * n2 * sizeof(float4)));
@@ -290,38 +295,41 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int which /* bit0 rows, bit1 height, bit2 maps */,
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int which /* bit0 rows, bit1 cols_b, bit2 disp */,
                                hipEvent_t* marks /* 4 events or null */)
 {
     using G = Geo<N>;
+    using HF = Half<N>;
     const unsigned tiles = c->tiles;
     hipError_t e;
-    constexpr size_t lds_rows = rows_lds_bytes<N, G::RP>();
-    constexpr size_t lds_h = sizeof(c32) * fft_lds_elems<N, G::CP>() + sizeof(float) * 2 * ((G::T_H + 63) / 64);
-    constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, G::CM>();
+    constexpr int C = G::CC;
+    constexpr size_t lds_rows = rows_lds_bytes<N>();
+    constexpr size_t lds_b = sizeof(c32) * fft_lds_elems<N, C>() + sizeof(float) * 2 * ((G::T_C + 63) / 64);
+    constexpr size_t lds_d = sizeof(c32) * fft_lds_elems<N, C>();
+    constexpr unsigned hb = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
     static bool attr_done = false;
     if (!attr_done) {
-        if ((e = allow_lds(k_rows<N, G::RP, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_cols_height<N, G::CP, G::T_H, typename G::PH>, lds_h)) != hipSuccess) return e;
-        if ((e = allow_lds(k_cols_maps<N, G::CM, G::T_M, typename G::PM>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_rows<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_cols_b<N, C, G::T_C, typename G::PC>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_cols_disp<N, C, G::T_C, typename G::PC>, lds_d)) != hipSuccess) return e;
         attr_done = true;
     }
     if (marks) (void)hipEventRecord(marks[0], c->stream);
     if (which & 1) {
-        unsigned gx = N / 2 / G::RP;
+        unsigned gx = N / 2 + 1;
 #ifdef OCEAN_STAMPS
-        if (const char* e = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(e);   // diagnostic: partial grid
+        if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
-        hipLaunchKernelGGL((k_rows<N, G::RP, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows,
+        hipLaunchKernelGGL((k_rows<N, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows,
                            c->stream, a);
     }
     if (marks) (void)hipEventRecord(marks[1], c->stream);
     if (which & 2)
-        hipLaunchKernelGGL((k_cols_height<N, G::CP, G::T_H, typename G::PH>), dim3(N / (2 * G::CP), tiles), dim3(G::T_H), lds_h,
+        hipLaunchKernelGGL((k_cols_b<N, C, G::T_C, typename G::PC>), dim3(hb + nb, tiles), dim3(G::T_C), lds_b,
                            c->stream, a);
     if (marks) (void)hipEventRecord(marks[2], c->stream);
     if (which & 4)
-        hipLaunchKernelGGL((k_cols_maps<N, G::CM, G::T_M, typename G::PM>), dim3(N / G::CM, tiles, 2), dim3(G::T_M), lds_m,
+        hipLaunchKernelGGL((k_cols_disp<N, C, G::T_C, typename G::PC>), dim3(nb, tiles), dim3(G::T_C), lds_d,
                            c->stream, a);
     if (marks) (void)hipEventRecord(marks[3], c->stream);
     return hipGetLastError();
@@ -546,7 +554,7 @@ int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, siz
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {
     (void)c;
-    return 108;   // 12 (h0 + omega) + 16*3.5 (intermediates) + 32 (maps) + 8 (raw height out + in)
+    return 108;   // SURVEY.md 8d accounting for the 7-field two-pass scheme; this pipeline moves 76 (ocean_kernels.h)
 }
 
 }  // extern "C"
