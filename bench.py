@@ -36,8 +36,8 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per texel each launch has to move in THIS pipeline (sum = 76).
 # SURVEY.md 8d's figure for the whole frame is 108 B/texel (7 fields, two-pass, no
 # point symmetry): the frame-level fraction below is quoted on that figure.
-KERNEL_BYTES = {"k_rows": 26, "k_cols_b": 28, "k_cols_disp": 22}
-KERNEL_ORDER = ["k_rows", "k_cols_b", "k_cols_disp"]
+KERNEL_BYTES = {"k_zpass": 26, "k_xpass_height": 4, "k_xpass_maps": 46}
+KERNEL_ORDER = ["k_zpass", "k_xpass_height", "k_xpass_maps"]
 FRAME_BYTES_SURVEY = 108.0
 
 

@@ -130,8 +130,18 @@ int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
  * internal buffers.                                                              */
 int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
 
-/* The hipStream_t the context enqueues on (as void*), and a way to replace it
- * with a caller-owned stream (NULL = back to the context's own).                 */
+/* Frame pipelining.  By default (depth 2) consecutive asynchronous frames
+ * alternate between two sets of intermediate buffers on two internal streams:
+ * the row pass of frame f+1 overlaps the column passes of frame f, the maps are
+ * still written strictly in frame order, and ocean_synchronize / every
+ * synchronous call drains both.  depth 1 = everything on one stream.  (The
+ * reference is strictly serial; its own DOUBLE_BUFFERED switch,
+ * WaterSurfaceMesh.h:34, is the same idea on the upload side.)                   */
+int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 or 2 */);
+
+/* The hipStream_t the most recent frame was enqueued on (as void*), and a way
+ * to make the context use ONE caller-owned stream instead (this also disables
+ * pipelining; NULL = back to the context's own streams).                         */
 void* ocean_stream(ocean_t* ctx);
 int   ocean_set_stream(ocean_t* ctx, void* hip_stream);
 

@@ -14,5 +14,5 @@ for n in sizes:
     per = ms / frames
     gb = 108.0 * n * n * tiles / (per * 1e-3) / 1e9
     print(f"N={n} tiles={tiles}: {per*1e3:.1f} us/frame  {1e3/per:.0f} frames/s  {n*n*tiles/per/1e6:.2f} Gtexel/s  "
-          f"alg {gb:.0f} GB/s ({gb/8000*100:.1f}% of 8TB/s)  kernels(us): rows {k[0]*1e3:.1f} cols_b {k[1]*1e3:.1f} disp {k[2]*1e3:.1f}")
+          f"alg {gb:.0f} GB/s ({gb/8000*100:.1f}% of 8TB/s)  kernels(us): zpass {k[0]*1e3:.1f} height {k[1]*1e3:.1f} maps {k[2]*1e3:.1f}")
     b.close()

@@ -5,7 +5,7 @@ import numpy as np
 import watersurfacerendering_amd as W
 from watersurfacerendering_amd import _abi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-nst = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+nst = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 b = W.OceanBatch(n, 1, 0); b.prepare(1)
 L = _abi.lib()
 L.ocean_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -13,10 +13,18 @@ for j in range(3): b.compute_waves_async(0.1 * j)
 b.synchronize()
 L.ocean_debug_stamps(b._h, 1, None, 0)
 b.compute_waves_async(1.0); b.synchronize()
-nb = n // 2
-out = np.zeros(nb * 16, dtype=np.uint64)
+nb = n // 2 + 8
+out = np.zeros(nb * 32, dtype=np.uint64)
 L.ocean_debug_stamps(b._h, 1, out.ctypes.data_as(C.c_void_p), out.size)
-st = out.reshape(nb, 16)[:, :nst].astype(np.int64)
+st = out.reshape(nb, 32).astype(np.int64)
+valid = st[:, 0] > 0
+print('valid blocks', valid.sum())
+full = st[valid]
+names = {0:'start',1:'S ready',2:'batchA end',3:'batchB end'}
+rel = full - full[:, :1]
+for k in range(32):
+    if (full[:, k] > 0).all(): print(f'  stamp {k:2d}: median {np.median(rel[:, k]):9.0f} cycles after start', names.get(k, ''))
+st = full[:, :nst]
 t0 = st[:, 0].min()
 d = np.diff(st, axis=1)
 print("blocks", nb, "span (cycles @100MHz?) first start -> last end:", st[:, nst-1].max() - t0)

@@ -26,6 +26,19 @@ namespace ocean {
 
 using c32 = float2;
 
+// diagnostic builds only (-DOCEAN_STAMPS): per-workgroup clock stamps
+#ifdef OCEAN_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(int k)
+{
+    if (threadIdx.x == 0 && g_stamps)
+        g_stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 32 + k] = clock64();
+}
+#define OCEAN_STAMP(k) ::ocean::stamp(k)
+#else
+#define OCEAN_STAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ c32 cmul(c32 a, c32 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -153,16 +166,76 @@ template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() *
 template <int C>
 __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
 
+// Base twiddles of every (stage, work item) of one thread, fetched ONCE per kernel
+// into registers (a handful of VGPRs): the table loads then overlap the kernel's
+// first global loads instead of sitting on the critical path of every transform.
+template <int N, int C, int T, class P> struct TwiddleRegs {
+    static constexpr int it_of(int stage) { return ((N / P::r[stage]) * C + T - 1) / T; }
+    static constexpr int itmax()
+    {
+        int m = 1;
+        for (int s = 0; s < P::S; ++s) m = it_of(s) > m ? it_of(s) : m;
+        return m;
+    }
+    c32 w[P::S][itmax()];
+
+    template <int STAGE, int NS>
+    __device__ __forceinline__ void load_from(const c32* __restrict__ tw, int tid)
+    {
+        constexpr int R = P::r[STAGE];
+        constexpr int ITEMS = (N / R) * C;
+        constexpr int IT = (ITEMS + T - 1) / T;
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int wi = tid + u * T;
+            const int j = (wi < ITEMS ? wi : 0) / C;
+            if constexpr (NS > 1) w[STAGE][u] = tw[(j % NS) * (N / (NS * R))];
+            else w[STAGE][u] = make_float2(1.f, 0.f);
+        }
+        if constexpr (STAGE + 1 < P::S) load_from<STAGE + 1, NS * R>(tw, tid);
+    }
+    __device__ __forceinline__ void load(const c32* __restrict__ tw, int tid) { load_from<0, 1>(tw, tid); }
+};
+
 // One Stockham stage over the whole batch.
-//   FIRST: inputs from in(idx, c);  otherwise from LDS
+//   FIRST: inputs from in(idx, c, u, i) (u, i are unrolled constants: the functor may
+//          serve values it prefetched into registers);  otherwise from LDS
 //   LAST : outputs to out(idx, c, value, u, i) (u, i are unrolled constants);
 //          otherwise to LDS, in place (reads complete -> barrier -> writes)
-template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, class In, class Out>
-__device__ __forceinline__ void fft_stage(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
+template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, class TW, class In, class Out>
+__device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
+    [[maybe_unused]] constexpr int STAMP_BASE = STAGE;
     constexpr int ITEMS = (N / R) * C;
     constexpr int IT = (ITEMS + T - 1) / T;
     constexpr bool GUARD = (ITEMS % T) != 0;
+    if constexpr (LAST) {
+        // nothing is written back to LDS: finish one work item at a time (R complex live, not IT*R)
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int w = tid + u * T;
+            if (!GUARD || w < ITEMS) {
+                const int c = w % C, j = w / C;
+                c32 x[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    if constexpr (FIRST) x[i] = in(j + i * (N / R), c, u, i);
+                    else x[i] = lds[lds_index<C>(j + i * (N / R), c)];
+                }
+#ifndef OCEAN_ABL_NOFFT
+                if constexpr (NS > 1) apply_twiddles<R>(x, twr.w[STAGE][u]);
+                Dft<R>::run(x);
+#endif
+                const int k = j % NS;
+                const int j0 = (j - k) * R + k;
+#pragma unroll
+                for (int i = 0; i < R; ++i) out(j0 + i * NS, c, x[i], u, i);
+            }
+        }
+        OCEAN_STAMP(8 + 3 * STAMP_BASE);
+        OCEAN_STAMP(9 + 3 * STAMP_BASE);
+        return;
+    }
     c32 x[IT][R];
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -171,19 +244,18 @@ __device__ __forceinline__ void fft_stage(c32* lds, const c32* __restrict__ tw, 
             const int c = w % C, j = w / C;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                if constexpr (FIRST) x[u][i] = in(j + i * (N / R), c);
+                if constexpr (FIRST) x[u][i] = in(j + i * (N / R), c, u, i);
                 else x[u][i] = lds[lds_index<C>(j + i * (N / R), c)];
             }
 #ifndef OCEAN_ABL_NOFFT
-            if constexpr (NS > 1) {
-                const int k = j % NS;
-                apply_twiddles<R>(x[u], tw[k * (N / (NS * R))]);
-            }
+            if constexpr (NS > 1) apply_twiddles<R>(x[u], twr.w[STAGE][u]);
             Dft<R>::run(x[u]);
 #endif
         }
     }
-    if constexpr (!LAST) __syncthreads();   // every reader of the old image is done
+    OCEAN_STAMP(8 + 3 * STAMP_BASE);
+    __syncthreads();   // every reader of the old image is done
+    OCEAN_STAMP(9 + 3 * STAMP_BASE);
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
         const int w = tid + u * T;
@@ -192,36 +264,55 @@ __device__ __forceinline__ void fft_stage(c32* lds, const c32* __restrict__ tw, 
             const int k = j % NS;
             const int j0 = (j - k) * R + k;
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                if constexpr (LAST) out(j0 + i * NS, c, x[u][i], u, i);
-                else lds[lds_index<C>(j0 + i * NS, c)] = x[u][i];
-            }
+            for (int i = 0; i < R; ++i) lds[lds_index<C>(j0 + i * NS, c)] = x[u][i];
         }
     }
 }
 
-template <int N, int C, int T, class P, int STAGE, int NS, class In, class Out>
-__device__ __forceinline__ void run_stages(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
+template <int N, int C, int T, class P, int STAGE, int NS, class TW, class In, class Out>
+__device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
     constexpr int R = P::r[STAGE];
     constexpr bool FIRST = STAGE == 0, LAST = STAGE == P::S - 1;
-    fft_stage<N, R, NS, C, T, FIRST, LAST>(lds, tw, tid, in, out);
+    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE>(lds, twr, tid, in, out);
+    OCEAN_STAMP(10 + 3 * STAGE);
     if constexpr (!LAST) {
         __syncthreads();
-        run_stages<N, C, T, P, STAGE + 1, NS * R>(lds, tw, tid, in, out);
+        run_stages<N, C, T, P, STAGE + 1, NS * R>(lds, twr, tid, in, out);
     }
 }
 
 // C interleaved length-N transforms by the T threads of the workgroup, radix
 // plan P (product of radices = N).  `lds` needs fft_lds_elems<N, C>() float2;
-// `tw[k] = exp(+2 pi i k / N)`.  The call may start while other waves still
-// read `lds` from a previous call: the first LDS write is preceded by a barrier.
+// `twr` = TwiddleRegs<N, C, T, P> loaded from the table tw[k] = exp(+2 pi i k / N).
+// The call may start while other waves still read `lds` from a previous call:
+// the first LDS write is preceded by a barrier.
 template <int N, int C, int T, class P = Plan<N>, class In, class Out>
-__device__ __forceinline__ void batch_fft(c32* lds, const c32* __restrict__ tw, int tid, In& in, Out& out)
+__device__ __forceinline__ void batch_fft(c32* lds, const TwiddleRegs<N, C, T, P>& twr, int tid, In& in, Out& out)
 {
     static_assert(P::product() == N, "radix plan does not match the transform length");
-    run_stages<N, C, T, P, 0, 1>(lds, tw, tid, in, out);
+    // Launder the base twiddles: otherwise the compiler hoists the whole power chain
+    // (up to 15 complex per stage) out of consecutive transforms and keeps ~90 VGPRs
+    // live across them -- recomputing 14 products per butterfly is far cheaper than
+    // the occupancy that costs.
+    TwiddleRegs<N, C, T, P> local = twr;
+#pragma unroll
+    for (int s = 0; s < P::S; ++s)
+#pragma unroll
+        for (int u = 0; u < TwiddleRegs<N, C, T, P>::itmax(); ++u)
+            asm volatile("" : "+v"(local.w[s][u].x), "+v"(local.w[s][u].y));
+    run_stages<N, C, T, P, 0, 1>(lds, local, tid, in, out);
 }
+
+// Mapping of the FIRST stage: work item w = tid + u*T reads inputs
+// idx = j + i*(N/R0), column c, with j = w / C, c = w % C  (in(idx, c, u, i)).
+template <int N, int C, int T, class P = Plan<N>> struct FirstStage {
+    static constexpr int R0 = P::r[0];
+    static constexpr int ITEMS = (N / R0) * C;
+    static constexpr int IT = (ITEMS + T - 1) / T;
+    static constexpr bool GUARD = (ITEMS % T) != 0;
+    static constexpr int STRIDE = N / R0;
+};
 
 // Mapping of the LAST stage: work item w = tid + u*T owns outputs
 // idx = j + i*(N/RL), column c, with j = w / C, c = w % C (k == j there).

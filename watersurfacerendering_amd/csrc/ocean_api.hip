@@ -32,9 +32,17 @@ struct ocean_ctx {
     uint32_t tiles = 0;
     int device = 0;
     bool prepared = false;
-    bool own_stream = true;
-    hipStream_t stream = nullptr;
-    hipStream_t own = nullptr;
+    // Frames alternate between two intermediate-buffer sets, each with its own
+    // stream, so the row pass of frame f+1 overlaps the column passes of frame f
+    // (pipeline depth 2).  Map writes stay in frame order (event chain).  A
+    // caller-supplied stream, or depth 1, runs everything on one stream / set 0.
+    hipStream_t own[2] = {nullptr, nullptr};
+    hipStream_t user = nullptr;
+    int depth = 1;
+    uint64_t frame_ctr = 0;
+    int last_set = 0;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool done_valid[2] = {false, false};
     std::vector<ocean_params> params;
     uint64_t seed = 0;
     // device state
@@ -42,10 +50,10 @@ struct ocean_ctx {
     float* omega = nullptr;
     float* k1d = nullptr;
     float2* tw = nullptr;
-    float2* z = nullptr;
-    float2* zh = nullptr;
-    float* hraw = nullptr;
-    unsigned* minmax = nullptr;
+    float2* z[2] = {nullptr, nullptr};
+    float2* zh[2] = {nullptr, nullptr};
+    float* hraw[2] = {nullptr, nullptr};
+    unsigned* minmax[2] = {nullptr, nullptr};
     float4* disp = nullptr;
     float4* nrm = nullptr;
     float4* ext_disp = nullptr;
@@ -62,13 +70,15 @@ struct ocean_ctx {
 
 static void free_device(ocean_ctx* c)
 {
-    void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->z, c->zh, c->hraw, c->minmax, c->disp, c->nrm,
-                    c->toff, c->lambda, c->tparams, c->xi};
+    void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->z[0], c->z[1], c->zh[0], c->zh[1], c->hraw[0], c->hraw[1],
+                    c->minmax[0], c->minmax[1], c->disp, c->nrm, c->toff, c->lambda, c->tparams, c->xi};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr; c->z = nullptr; c->zh = nullptr;
-    c->hraw = nullptr; c->minmax = nullptr; c->disp = nullptr; c->nrm = nullptr; c->toff = nullptr;
+    c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr;
+    for (int i = 0; i < 2; ++i) { c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr; }
+    c->disp = nullptr; c->nrm = nullptr; c->toff = nullptr;
     c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
     c->prepared = false;
+    c->done_valid[0] = c->done_valid[1] = false;
 }
 
 static bool size_ok(uint32_t n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
@@ -83,13 +93,15 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMalloc(&c->tw, n * sizeof(float2)));
     // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
     const size_t nu = n / 2 + 1, nup = n / 2 + 8;
-    HIP_TRY(hipMalloc(&c->z, t * 3 * nu * 2 * nup * sizeof(float2)));
-    HIP_TRY(hipMalloc(&c->zh, t * nu * nup * sizeof(float2)));
-    HIP_TRY(hipMalloc(&c->hraw, t * nup * n * sizeof(float)));
-    HIP_TRY(hipMemset(c->z, 0, t * 3 * nu * 2 * nup * sizeof(float2)));
-    HIP_TRY(hipMemset(c->zh, 0, t * nu * nup * sizeof(float2)));
-    HIP_TRY(hipMemset(c->hraw, 0, t * nup * n * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->minmax, t * 2 * sizeof(unsigned)));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(&c->z[i], t * 3 * nu * 2 * nup * sizeof(float2)));
+        HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
+        HIP_TRY(hipMalloc(&c->hraw[i], t * nup * n * sizeof(float)));
+        HIP_TRY(hipMemset(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2)));
+        HIP_TRY(hipMemset(c->zh[i], 0, t * nu * nup * sizeof(float2)));
+        HIP_TRY(hipMemset(c->hraw[i], 0, t * nup * n * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
+    }
     HIP_TRY(hipMalloc(&c->disp, t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->nrm, t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->toff, t * sizeof(float)));
@@ -105,6 +117,17 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMemcpy(c->tw, tw.data(), n * sizeof(float2), hipMemcpyHostToDevice));
     return OCEAN_OK;
 }
+
+static hipStream_t stream_of(const ocean_ctx* c, int set) { return c->user ? c->user : c->own[set]; }
+
+static int sync_all(ocean_ctx* c)
+{
+    for (int i = 0; i < 2; ++i)
+        if (c->own[i]) HIP_TRY(hipStreamSynchronize(c->own[i]));
+    if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
+    return OCEAN_OK;
+}
+#define SYNC_ALL(c) do { int rc_ = sync_all(c); if (rc_) return rc_; } while (0)
 
 extern "C" {
 
@@ -157,8 +180,11 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
     int rc = OCEAN_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = OCEAN_E_HIP; break; }
-        if (hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking) != hipSuccess) { rc = OCEAN_E_HIP; break; }
-        c->stream = c->own;
+        for (int i = 0; i < 2 && !rc; ++i) {
+            if (hipStreamCreateWithFlags(&c->own[i], hipStreamNonBlocking) != hipSuccess) rc = OCEAN_E_HIP;
+            else if (hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) != hipSuccess) rc = OCEAN_E_HIP;
+        }
+        if (rc) break;
         if (hipHostMalloc((void**)&c->h_minmax, tiles * 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         if (rc) break;
@@ -173,11 +199,14 @@ void ocean_destroy(ocean_t* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    if (c->own) (void)hipStreamDestroy(c->own);
+    for (int i = 0; i < 2; ++i) {
+        if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+        if (c->own[i]) (void)hipStreamDestroy(c->own[i]);
+    }
     delete c;
 }
 
@@ -214,7 +243,7 @@ int ocean_set_lambda(ocean_t* c, uint32_t tile, float lambda)
         l[i] = c->params[i].lambda;
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     HIP_TRY(hipMemcpy(c->lambda, l.data(), c->tiles * sizeof(float), hipMemcpyHostToDevice));
     return OCEAN_OK;
 }
@@ -226,7 +255,7 @@ int ocean_set_tile_size(ocean_t* c, uint32_t tile_size)
     if (!size_ok(tile_size)) return OCEAN_E_UNSUPPORTED;
     if (tile_size == c->n) return OCEAN_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     free_device(c);
     c->n = tile_size;
     c->ext_disp = nullptr; c->ext_nrm = nullptr;
@@ -261,21 +290,21 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         tp[i].seed = seed + i;
         lam[i] = p.lambda;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     HIP_TRY(hipMemcpy(c->tparams, tp.data(), t * sizeof(TileParams), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->lambda, lam.data(), t * sizeof(float), hipMemcpyHostToDevice));
     if (!c->xi) HIP_TRY(hipMalloc(&c->xi, t * n2 * sizeof(float2)));
     if (xi_or_null) HIP_TRY(hipMemcpy(c->xi, xi_or_null, t * n2 * sizeof(float2), hipMemcpyHostToDevice));
     {
         dim3 g((unsigned)((n + 255) / 256), (unsigned)t);
-        hipLaunchKernelGGL(k_init_k1d, g, dim3(256), 0, c->stream, c->k1d, c->tparams, (int)n);
+        hipLaunchKernelGGL(k_init_k1d, g, dim3(256), 0, stream_of(c, 0), c->k1d, c->tparams, (int)n);
         dim3 g2((unsigned)((n2 + 255) / 256), (unsigned)t);
-        hipLaunchKernelGGL(k_init_spectrum, g2, dim3(256), 0, c->stream, c->h0, c->omega,
+        hipLaunchKernelGGL(k_init_spectrum, g2, dim3(256), 0, stream_of(c, 0), c->h0, c->omega,
                            xi_or_null ? (float2*)nullptr : c->xi, xi_or_null ? c->xi : (const float2*)nullptr,
                            c->k1d, c->tparams, (int)n);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     c->seed = seed;
     c->prepared = true;
     return OCEAN_OK;
@@ -295,73 +324,106 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int which /* bit0 rows, bit1 cols_b, bit2 disp */,
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st, hipEvent_t wait_before_cols,
                                hipEvent_t* marks /* 4 events or null */)
 {
     using G = Geo<N>;
     using HF = Half<N>;
     const unsigned tiles = c->tiles;
     hipError_t e;
-    constexpr int C = G::CC;
-    constexpr size_t lds_rows = rows_lds_bytes<N>();
-    constexpr size_t lds_b = sizeof(c32) * fft_lds_elems<N, C>() + sizeof(float) * 2 * ((G::T_C + 63) / 64);
-    constexpr size_t lds_d = sizeof(c32) * fft_lds_elems<N, C>();
-    constexpr unsigned hb = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
+    constexpr int C = G::CC, CH = G::CH;
+    constexpr size_t lds_rows = zpass_lds_bytes<N>();
+    constexpr size_t lds_h = sizeof(c32) * fft_lds_elems<N, CH>() + sizeof(float) * 2 * ((G::T_H + 63) / 64);
+    constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
+    static_assert(HF::NUP % (2 * CH) == 0, "height row blocks");
+    constexpr unsigned hb = HF::NUP / (2 * CH), nb = (HF::NU + C - 1) / C;
     static bool attr_done = false;
     if (!attr_done) {
-        if ((e = allow_lds(k_rows<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_cols_b<N, C, G::T_C, typename G::PC>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_cols_disp<N, C, G::T_C, typename G::PC>, lds_d)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_height<N, CH, G::T_H, typename G::PC>, lds_h)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
         attr_done = true;
     }
-    if (marks) (void)hipEventRecord(marks[0], c->stream);
-    if (which & 1) {
+#ifdef OCEAN_STAMPS
+    // diagnostic: stamps are recorded for ONE kernel of the frame (env OCEAN_DEBUG_STAMP_KERNEL = 0, 1, 2)
+    static unsigned long long* null_ptr = nullptr;
+    const int stamp_k = getenv("OCEAN_DEBUG_STAMP_KERNEL") ? atoi(getenv("OCEAN_DEBUG_STAMP_KERNEL")) : 0;
+    auto arm = [&](int k) {
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(ocean::g_stamps), (k == stamp_k && c->stamps) ? &c->stamps : &null_ptr,
+                                     sizeof(c->stamps), 0, hipMemcpyHostToDevice, st);
+    };
+    arm(0);
+#endif
+    if (marks) (void)hipEventRecord(marks[0], st);
+    {
         unsigned gx = N / 2 + 1;
 #ifdef OCEAN_STAMPS
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
-        hipLaunchKernelGGL((k_rows<N, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows,
-                           c->stream, a);
+        hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows, st, a);
     }
-    if (marks) (void)hipEventRecord(marks[1], c->stream);
-    if (which & 2)
-        hipLaunchKernelGGL((k_cols_b<N, C, G::T_C, typename G::PC>), dim3(hb + nb, tiles), dim3(G::T_C), lds_b,
-                           c->stream, a);
-    if (marks) (void)hipEventRecord(marks[2], c->stream);
-    if (which & 4)
-        hipLaunchKernelGGL((k_cols_disp<N, C, G::T_C, typename G::PC>), dim3(nb, tiles), dim3(G::T_C), lds_d,
-                           c->stream, a);
-    if (marks) (void)hipEventRecord(marks[3], c->stream);
+    if (marks) (void)hipEventRecord(marks[1], st);
+#ifdef OCEAN_STAMPS
+    if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
+    arm(1);
+#endif
+    hipLaunchKernelGGL((k_xpass_height<N, CH, G::T_H, typename G::PC>), dim3(hb, tiles), dim3(G::T_H), lds_h, st, a);
+    if (marks) (void)hipEventRecord(marks[2], st);
+    // the maps are shared by all frames: this frame may only start writing them
+    // once the previous frame (other stream) has finished its own
+    if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
+#ifdef OCEAN_STAMPS
+    arm(2);
+#endif
+    {
+        unsigned gd = nb;
+#ifdef OCEAN_STAMPS
+        if (const char* ev = getenv("OCEAN_DEBUG_DISP_GRID")) gd = (unsigned)atoi(ev);
+#endif
+        hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC>), dim3(gd, tiles), dim3(G::T_C), lds_m, st, a);
+    }
+    if (marks) (void)hipEventRecord(marks[3], st);
     return hipGetLastError();
 }
 
-static int enqueue_frame(ocean_ctx* c, float t, int which, hipEvent_t* marks)
+// Enqueues one frame.  pipelined = use the two-set / two-stream scheme.
+static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks)
 {
     if (!c) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
+    const bool pipe = pipelined && c->depth == 2 && !c->user;
+    const int set = pipe ? (int)(c->frame_ctr & 1) : c->last_set;
+    hipStream_t st = stream_of(c, set);
+    hipEvent_t wait = nullptr;
+    if (pipe && c->done_valid[1 - set]) wait = c->done[1 - set];
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
-    a.z = c->z; a.zh = c->zh; a.hraw = c->hraw; a.minmax = c->minmax;
+    a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.disp = c->ext_disp ? c->ext_disp : c->disp;
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrm;
     a.toff = c->use_toff ? c->toff : nullptr;
     a.lambda = c->lambda;
     a.t = t;
-    a.stamps = c->stamps;
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
-        case 16: e = launch_frame<16>(c, a, which, marks); break;
-        case 32: e = launch_frame<32>(c, a, which, marks); break;
-        case 64: e = launch_frame<64>(c, a, which, marks); break;
-        case 128: e = launch_frame<128>(c, a, which, marks); break;
-        case 256: e = launch_frame<256>(c, a, which, marks); break;
-        case 512: e = launch_frame<512>(c, a, which, marks); break;
-        case 1024: e = launch_frame<1024>(c, a, which, marks); break;
-        case 2048: e = launch_frame<2048>(c, a, which, marks); break;
-        case 4096: e = launch_frame<4096>(c, a, which, marks); break;
+        case 16: e = launch_frame<16>(c, a, st, wait, marks); break;
+        case 32: e = launch_frame<32>(c, a, st, wait, marks); break;
+        case 64: e = launch_frame<64>(c, a, st, wait, marks); break;
+        case 128: e = launch_frame<128>(c, a, st, wait, marks); break;
+        case 256: e = launch_frame<256>(c, a, st, wait, marks); break;
+        case 512: e = launch_frame<512>(c, a, st, wait, marks); break;
+        case 1024: e = launch_frame<1024>(c, a, st, wait, marks); break;
+        case 2048: e = launch_frame<2048>(c, a, st, wait, marks); break;
+        case 4096: e = launch_frame<4096>(c, a, st, wait, marks); break;
         default: return OCEAN_E_UNSUPPORTED;
     }
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
+    if (pipe) {
+        HIP_TRY(hipEventRecord(c->done[set], st));
+        c->done_valid[set] = true;
+        c->frame_ctr++;
+    }
+    c->last_set = set;
     return OCEAN_OK;
 }
 
@@ -371,21 +433,21 @@ int ocean_compute_waves_async(ocean_t* c, float t)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    return enqueue_frame(c, t, 7, nullptr);
+    return enqueue_frame(c, t, true, nullptr);
 }
 
 int ocean_synchronize(ocean_t* c)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     return OCEAN_OK;
 }
 
 static int fetch_minmax(ocean_ctx* c)
 {
-    HIP_TRY(hipMemcpyAsync(c->h_minmax, c->minmax, c->tiles * 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
+    HIP_TRY(hipMemcpy(c->h_minmax, c->minmax[c->last_set], c->tiles * 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
     return OCEAN_OK;
 }
 
@@ -401,7 +463,7 @@ int ocean_compute_waves(ocean_t* c, float t, float* out_amp)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = enqueue_frame(c, t, 7, nullptr);
+    int rc = enqueue_frame(c, t, true, nullptr);
     if (rc) return rc;
     rc = fetch_minmax(c);
     if (rc) return rc;
@@ -414,7 +476,7 @@ int ocean_set_time_offsets(ocean_t* c, const float* offsets)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     if (!offsets) { c->use_toff = false; return OCEAN_OK; }
     HIP_TRY(hipMemcpy(c->toff, offsets, c->tiles * sizeof(float), hipMemcpyHostToDevice));
     c->use_toff = true;
@@ -441,9 +503,9 @@ int ocean_read_maps(ocean_t* c, uint32_t first, uint32_t count, float* disp, flo
     const size_t n2 = (size_t)c->n * c->n;
     const float4* d = (c->ext_disp ? c->ext_disp : c->disp) + first * n2;
     const float4* q = (c->ext_nrm ? c->ext_nrm : c->nrm) + first * n2;
-    if (disp) HIP_TRY(hipMemcpyAsync(disp, d, count * n2 * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    if (nrm) HIP_TRY(hipMemcpyAsync(nrm, q, count * n2 * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
+    if (disp) HIP_TRY(hipMemcpy(disp, d, count * n2 * sizeof(float4), hipMemcpyDeviceToHost));
+    if (nrm) HIP_TRY(hipMemcpy(nrm, q, count * n2 * sizeof(float4), hipMemcpyDeviceToHost));
     return OCEAN_OK;
 }
 
@@ -460,20 +522,22 @@ int ocean_bind_output(ocean_t* c, void* d_disp, void* d_nrm)
     if (!c) return OCEAN_E_INVALID;
     if (((uintptr_t)d_disp | (uintptr_t)d_nrm) & 15u) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     c->ext_disp = (float4*)d_disp;
     c->ext_nrm = (float4*)d_nrm;
     return OCEAN_OK;
 }
 
-void* ocean_stream(ocean_t* c) { return c ? (void*)c->stream : nullptr; }
+void* ocean_stream(ocean_t* c) { return c ? (void*)stream_of(c, c->last_set) : nullptr; }
 
 int ocean_set_stream(ocean_t* c, void* s)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own;
+    SYNC_ALL(c);
+    c->user = (hipStream_t)s;
+    c->last_set = 0;
+    c->done_valid[0] = c->done_valid[1] = false;
     return OCEAN_OK;
 }
 
@@ -483,9 +547,22 @@ int ocean_read_spectrum(ocean_t* c, uint32_t tile, float* h0, float* omega)
     if (!c->prepared) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h0) HIP_TRY(hipMemcpy(h0, c->h0 + tile * n2, n2 * sizeof(float2), hipMemcpyDeviceToHost));
-    if (omega) HIP_TRY(hipMemcpy(omega, c->omega + tile * n2, n2 * sizeof(float), hipMemcpyDeviceToHost));
+    SYNC_ALL(c);
+    // device storage is transposed ([kx index][kz index]); hand back the reference's row-major [m][n]
+    const size_t n = c->n;
+    if (h0) {
+        std::vector<float2> tmp(n2);
+        HIP_TRY(hipMemcpy(tmp.data(), c->h0 + tile * n2, n2 * sizeof(float2), hipMemcpyDeviceToHost));
+        float2* out = reinterpret_cast<float2*>(h0);
+        for (size_t q = 0; q < n; ++q)
+            for (size_t m = 0; m < n; ++m) out[m * n + q] = tmp[q * n + m];
+    }
+    if (omega) {
+        std::vector<float> tmp(n2);
+        HIP_TRY(hipMemcpy(tmp.data(), c->omega + tile * n2, n2 * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < n; ++q)
+            for (size_t m = 0; m < n; ++m) omega[m * n + q] = tmp[q * n + m];
+    }
     return OCEAN_OK;
 }
 
@@ -495,8 +572,18 @@ int ocean_read_xi(ocean_t* c, uint32_t tile, float* xi)
     if (!c->prepared || !c->xi) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     HIP_TRY(hipMemcpy(xi, c->xi + tile * n2, n2 * sizeof(float2), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int ocean_set_pipeline_depth(ocean_t* c, int depth)
+{
+    if (!c || (depth != 1 && depth != 2)) return OCEAN_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    c->depth = depth;
+    c->done_valid[0] = c->done_valid[1] = false;
     return OCEAN_OK;
 }
 
@@ -507,22 +594,24 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     for (int j = 0; j < warmup; ++j)
-        if ((rc = enqueue_frame(c, t0 + dt * (float)j, 7, nullptr))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        if ((rc = enqueue_frame(c, t0 + dt * (float)j, true, nullptr))) return rc;
+    SYNC_ALL(c);
+    HIP_TRY(hipEventRecord(c->ev[4], stream_of(c, (int)(c->frame_ctr & 1))));
     for (int j = 0; j < frames; ++j)
-        if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), 7, nullptr))) return rc;
-    HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+        if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), true, nullptr))) return rc;
+    // frame f's column passes wait for frame f-1's, so the last frame ends last
+    HIP_TRY(hipEventRecord(c->ev[5], stream_of(c, c->last_set)));
     HIP_TRY(hipEventSynchronize(c->ev[5]));
+    SYNC_ALL(c);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     if (ms_total) *ms_total = ms;
     if (ms_kernel) {
-        // second pass: events around every launch (adds event overhead, so it is
-        // reported separately from ms_total and never mixed into it)
+        // second pass, one frame at a time on one stream: events around every
+        // launch (adds event overhead; reported separately, never mixed into ms_total)
         double acc[3] = {0, 0, 0};
         for (int j = 0; j < frames; ++j) {
-            if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), 7, c->ev))) return rc;
+            if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), false, c->ev))) return rc;
             HIP_TRY(hipEventSynchronize(c->ev[3]));
             for (int k = 0; k < 3; ++k) {
                 float m = 0.f;
@@ -541,7 +630,7 @@ int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, siz
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    SYNC_ALL(c);
     if (enable && !c->stamps) {
         HIP_TRY(hipMalloc(&c->stamps, (size_t)1 << 24));
         HIP_TRY(hipMemset(c->stamps, 0, (size_t)1 << 24));

@@ -19,11 +19,11 @@
 //               -m, S+ = (a+b)/2, S- = (a-b)/2, build the three packed pairs and
 //               the height from S+/S- and the wave-vector coefficients, four
 //               row (x-axis) inverse FFTs.
-//   k_cols_b    column (z-axis) pass, part 1, one launch, two kinds of
+//   k_xpass_b    column (z-axis) pass, part 1, one launch, two kinds of
 //               workgroup: HEIGHT (two real columns per complex transform,
 //               sign, raw heights out, global min/max by atomics) and NORMAL
 //               (pairs 1 and 2 -> finished normal map, both mirror halves).
-//   k_cols_disp part 2, needs the min/max: pair 0 + raw height -> displacement map.
+//   k_xpass_disp part 2, needs the min/max: pair 0 + raw height -> displacement map.
 //
 // HBM bytes per texel actually moved (this pipeline): 12 (h0, omega) + 14 + 14
 // (half-size intermediates out and in) + 2 + 2 (raw height) + 32 (maps) = 76,
@@ -48,8 +48,8 @@ struct TileParams {          // device copy of one tile's properties
 };
 
 struct FrameArgs {
-    const float2* h0;        // [tiles][N][N]   base amplitudes h0(k)
-    const float* omega;      // [tiles][N][N]   quantised dispersion
+    const float2* h0;        // [tiles][N][N]   base amplitudes h0(k), TRANSPOSED: [n (kx index)][m (kz index)]
+    const float* omega;      // [tiles][N][N]   quantised dispersion, same layout
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
     const float2* tw;        // [N]             exp(+2 pi i k / N)
     float2* z;               // [tiles][3][N/2+1][2][NUP] row-transformed pairs: row m, side 0 = columns
@@ -62,14 +62,9 @@ struct FrameArgs {
     const float* toff;       // [tiles] or null
     const float* lambda;     // [tiles]
     float t;
-    unsigned long long* stamps;   // diagnostic builds only (-DOCEAN_STAMPS), else null
 };
 
-#ifdef OCEAN_STAMPS
-#define OCEAN_STAMP(k) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + (k)] = clock64(); } while (0)
-#else
-#define OCEAN_STAMP(k) do {} while (0)
-#endif
+
 
 // ---- float <-> order-preserving unsigned key (for atomicMin/atomicMax) -----
 __host__ __device__ inline unsigned float_key(float f)
@@ -144,12 +139,16 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n2) return;
     const TileParams p = tp[tile];
-    const int m = (int)(i / n), q = (int)(i % n);
+    // the spectrum is stored TRANSPOSED: element i holds wave index (m, q) = (i % n, i / n),
+    // so that a spectrum column (fixed kx) is one contiguous run for the first pass.
+    // The gaussian draw of texel (m, q) keeps the reference's row-major index m*n + q.
+    const int q = (int)(i / n), m = (int)(i % n);
+    const size_t ref = (size_t)m * n + q;
     const float kx = k1d[(size_t)tile * n + q], kz = k1d[(size_t)tile * n + m];
     const float d = kx * kx + kz * kz;
     const float k = sqrtf(d);
-    const float2 g = xi_in ? xi_in[tile * n2 + i] : gauss_pair(p.seed, i);
-    if (xi_out) xi_out[tile * n2 + i] = g;
+    const float2 g = xi_in ? xi_in[tile * n2 + ref] : gauss_pair(p.seed, ref);
+    if (xi_out) xi_out[tile * n2 + ref] = g;
     float2 a = make_float2(0.f, 0.f);
     float w = 0.f;
     if (k > 0.00001f) {
@@ -169,21 +168,59 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
 // h~(k, t): WaveHeightFT (.h:265-275).  conj(h0(-k)) of the reference equals
 // conj(h0(k)) (same gaussian draw, Phillips even in k: .cpp:131-135), so
 //   h~ = h0 e^{i wt} + conj(h0) e^{-i wt} = 2 (Re h0 cos wt - Im h0 sin wt)  exactly real.
-// omega*t is ONE fp32 multiply like the reference; sincosf is the accurate
-// (Payne-Hanek backed) one since wt reaches 1e4 rad.
+// omega*t is ONE fp32 multiply like the reference, then an accurate sincos (wt reaches 1e4 rad).
 // ============================================================================
-__device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
+// sin and cos of an fp32 angle, both within ~1.5 ulp (9e-8 abs) for |x| < 1e5 rad:
+// three-term Cody-Waite reduction by pi/2 carried by FMAs, then the Cephes
+// single-precision minimax polynomials on [-pi/4, pi/4].  About 25 VALU
+// instructions for the pair (ocml's sincosf, with its Payne-Hanek branch, costs ~3x
+// that and was ~45% of the z pass).  Larger angles take the library path.
+__device__ __forceinline__ void sincos_f32(float x, float& s, float& c)
+{
+    if (__builtin_expect(fabsf(x) >= 1.0e5f, 0)) {
+        sincosf(x, &s, &c);
+        return;
+    }
+    const float fn = rintf(x * 0.636619772f);
+    float r = __builtin_fmaf(fn, -1.57079601e+00f, x);
+    r = __builtin_fmaf(fn, -3.13916473e-07f, r);
+    r = __builtin_fmaf(fn, -5.39030253e-15f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(pc * z, z, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int q = (int)fn;
+    float so = (q & 1) ? cs : sn;
+    float co = (q & 1) ? sn : cs;
+    s = (q & 2) ? -so : so;
+    c = ((q + 1) & 2) ? -co : co;
+}
+
+__device__ __forceinline__ float mul_nocontract(float a, float b)
 {
 #pragma clang fp contract(off)
-    const float wt = w * t;
+    return a * b;
+}
+__device__ __forceinline__ float height_re(float h0r, float h0i, float c, float s)
+{
+#pragma clang fp contract(off)
+    const float re = h0r * c - h0i * s;
+    return re + re;
+}
+
+__device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
+{
+    const float wt = mul_nocontract(w, t);      // ONE fp32 multiply, like the reference (.h:267)
     float s, c;
 #ifdef OCEAN_ABL_SINCOS
     s = wt * 1e-4f; c = 1.0f - s;
 #else
-    sincosf(wt, &s, &c);
+    sincos_f32(wt, s, c);
 #endif
-    const float re = h0r * c - h0i * s;
-    return re + re;
+    return height_re(h0r, h0i, c, s);
 }
 
 // ---- half-spectrum storage geometry -------------------------------------------
@@ -195,7 +232,7 @@ template <int N> struct Half {
     static constexpr size_t ZH_TILE = (size_t)NU * NUP;
     static constexpr size_t HRAW_TILE = (size_t)NUP * N;          // floats
 };
-__device__ __forceinline__ size_t hraw_index(int n, int p, int u) { return ((size_t)(u >> 3) * n + p) * 8 + (u & 7); }
+__device__ __forceinline__ unsigned hraw_index(int n, int p, int u) { return (unsigned)(((u >> 3) * n + p) * 8 + (u & 7)); }
 
 // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give the
 // workgroups that share an XCD (same id % 8) consecutive column blocks: lines
@@ -206,41 +243,129 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
 }
 
+// The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
+// column nb == 0, the only one where Tx = S- along the whole column.
+template <int N, int T, class P, bool COL0>
+__device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
+                                                 const TwiddleRegs<N, 2, T, P>& twr, float kx, float sm0, int tid,
+                                                 int tile, int nb)
+{
+    using HF = Half<N>;
+    const float kx2 = kx * kx;
+    float2* __restrict__ zt = a.z + (size_t)tile * HF::Z_TILE + (size_t)nb * 2 * HF::NUP;
+    float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE + (size_t)nb * HF::NUP;
+    // S+(e) and Tx(e), Tz(e)
+    auto fetch = [&](int e, float& sv, float& tx, float& tz) {
+        if constexpr (COL0) {
+            const float g1 = sp[e], g2 = sp[(N - e) & (N - 1)];
+            sv = 0.5f * (g1 + g2);
+            tx = 0.5f * (g1 - g2);
+            tz = (e == 0) ? tx : sv;
+        } else {
+            sv = sp[e];
+            tx = sv;
+            tz = (e == 0) ? sm0 : sv;
+        }
+    };
+    // -- batch A: slot 0 = pair 0 (Dx, Dz), slot 1 = pair 1 (sx, sz) ------------
+    {
+        auto in = [&](int e, int c, int, int) -> c32 {
+            float sv, tx, tz;
+            fetch(e, sv, tx, tz);
+#ifdef OCEAN_ABL_NOIN
+            return make_float2(sv, tx);
+#endif
+            const float kz = kzt[e];
+            const float d = kx2 + kz * kz;
+            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;      // |k| > 1e-5 (.h:135)
+            const float f = c ? -1.0f : inv;                       // pair 1: (-kz Tz, kx Tx); pair 0: (uz Tz, -ux Tx)
+            return make_float2(kz * f * tz, -kx * f * tx);
+        };
+        auto out = [&](int p, int c, c32 v, int, int) {
+#ifdef OCEAN_ABL_NOSTORE
+            asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
+#endif
+            // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored
+            // positions 0 and N/2 exist on side 0 only: the x pass knows)
+            zt[(unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))] = v;
+        };
+        batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
+        OCEAN_STAMP(2);
+    }
+    // -- batch B: slot 0 = pair 2 (dDx/dx, dDz/dz), slot 1 = height ----------------
+    {
+        auto in = [&](int e, int c, int, int) -> c32 {
+            float sv, tx, tz;
+            fetch(e, sv, tx, tz);
+#ifdef OCEAN_ABL_NOIN
+            return make_float2(sv, tx);
+#endif
+            const float kz = kzt[e];
+            const float kz2 = kz * kz;
+            const float d = kx2 + kz2;
+            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;
+            const float g = inv * sv;
+            return make_float2(c ? sv : kx2 * g, c ? 0.0f : kz2 * g);
+        };
+        auto out = [&](int p, int c, c32 v, int, int) {
+#ifdef OCEAN_ABL_NOSTORE
+            asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
+#endif
+            if (c) {
+                if (p <= N / 2) zh[(unsigned)p] = v;                // real input: other half is the conjugate
+                return;
+            }
+            zt[(unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))] = v;
+        };
+        batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
+        OCEAN_STAMP(3);
+    }
+}
+
 // ============================================================================
-// k_rows: workgroup = spectrum row m (blockIdx.x in [0, N/2]); mirror row
-// mb = (N-m)%N.  a(n) = h~(m,n), b(n) = h~(mb,(N-n)%N).
-//   S+ = (a+b)/2, S- = (a-b)/2;   Tx = (n==0 ? S- : S+), Tz = (m==0 ? S- : S+)
+// k_zpass (first pass, z axis): workgroup = spectrum COLUMN nb (kx index,
+// blockIdx.x in [0, N/2]); mirror column nbb = (N-nb)%N.  Both are contiguous
+// runs of the transposed spectrum.  Along the column, e = kz index:
+//   a(e) = h~(e, nb), b(e) = h~((N-e)%N, nbb)
+//   S+ = (a+b)/2, S- = (a-b)/2;   Tx = (nb==0 ? S- : S+), Tz = (e==0 ? S- : S+)
 //   (k(-idx) = -k(idx) except on the self-mirrored Nyquist row/column 0)
 //   pair 0: Dx_h + i Dz_h     = ( uz*Tz, -ux*Tx)      odd   (c = -i u, .cpp:323-326)
 //   pair 1: sx_h + i sz_h     = (-kz*Tz,  kx*Tx)      odd   (c =  i k, .cpp:309-310)
 //   pair 2: dxDx_h + i dzDz_h = (kx*ux*S+, kz*uz*S+)  even  (.cpp:327-330)
 //   height: S+                                         even
-// Two batches of two interleaved transforms: {pair 0, pair 1}, {pair 2, height}.
+// Two batches of two interleaved transforms over e: {pair 0, pair 1}, {pair 2, height};
+// output index p = z position; stored per column nb as side 0 (p <= N/2) / side 1 (N-p).
 // ============================================================================
+#ifndef OCEAN_ZPASS_MINW
+#define OCEAN_ZPASS_MINW 1
+#endif
 template <int N, int T, class P = Plan<N>>
-__global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
+__global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // 2 interleaved transforms
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());    // S+ [N]
-    float* sm = sp + N;                                                    // S- [N]
-    float* raw = reinterpret_cast<float*>(fbuf);                           // h~ rows m, mb (before the FFTs)
+    float* kzt = sp + N;                                                   // kz table [N]
+    float* raw = reinterpret_cast<float*>(fbuf);                           // h~ columns nb, nbb (before the FFTs)
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    const int m = blockIdx.x;
-    const int mb = (N - m) & (N - 1);
+    const int nb = blockIdx.x;
+    const int nbb = (N - nb) & (N - 1);
     const size_t n2 = (size_t)N * N;
     const float2* __restrict__ h0 = a.h0 + tile * n2;
     const float* __restrict__ om = a.omega + tile * n2;
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;               // [N], cache-resident table
+    const bool col0 = (nb == 0);
 
     OCEAN_STAMP(0);
-    // -- phase 1: animate rows m and mb; all loads issued before the first sincos
+    TwiddleRegs<N, 2, T, P> twr;
+    twr.load(a.tw, tid);
+    // -- phase 1: animate columns nb and nbb; all loads issued before the first sincos
     {
-        constexpr int ELEMS = N;                      // 2 rows * N/2 texel pairs
+        constexpr int ELEMS = N;                      // 2 columns * N/2 element pairs
         constexpr int P1 = (ELEMS + T - 1) / T;
         constexpr int PB = P1 > 4 ? 4 : P1;
         static_assert(P1 % PB == 0, "phase-1 batches");
@@ -254,7 +379,7 @@ __global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
                 if (ELEMS % T == 0 || e < ELEMS) {
                     const int s = e / (N / 2);
                     const int n = (e % (N / 2)) * 2;
-                    const size_t g = (size_t)(s ? mb : m) * N + n;
+                    const size_t g = (size_t)(s ? nbb : nb) * N + n;
 #ifdef OCEAN_ABL_NOLOAD
                     hv[u] = make_float4(1.f + g, 2.f, 3.f, 4.f); wv[u] = make_float2(0.5f, 0.25f);
 #else
@@ -283,87 +408,24 @@ __global__ void __launch_bounds__(T) k_rows(const FrameArgs a)
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
     }
     __syncthreads();
-    for (int n = tid; n < N; n += T) {
-        const float av = raw[n], bv = raw[N + ((N - n) & (N - 1))];
-        sp[n] = 0.5f * (av + bv);
-        sm[n] = 0.5f * (av - bv);
+    // S- is needed along the whole column only for the Nyquist column nb == 0 (Tx = S-);
+    // every other column needs just S-(0) (Tz at e == 0) and keeps the kz table in LDS instead.
+    // Nyquist column nb == 0 pairs with itself (nbb == 0): S+ is even and S- odd along e,
+    // so ONE array G(e) = h~(e, 0) carries both; every other column stores S+ directly.
+    const float sm0 = 0.5f * (raw[0] - raw[N]);
+    for (int e = tid; e < N; e += T) {
+        const float av = raw[e], bv = raw[N + ((N - e) & (N - 1))];
+        sp[e] = col0 ? av : 0.5f * (av + bv);
+        kzt[e] = k1[e];
     }
     __syncthreads();
     OCEAN_STAMP(1);
 
-    const float kz = k1[m];
-    const float kz2 = kz * kz;
-    const bool row0 = (m == 0);
-    float2* __restrict__ zt = a.z + (size_t)tile * HF::Z_TILE + (size_t)m * 2 * HF::NUP;
-    float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE + (size_t)m * HF::NUP;
-
-    // -- batch A: slot 0 = pair 0 (Dx, Dz), slot 1 = pair 1 (sx, sz) ------------
-    {
-        auto in = [&](int n, int c) -> c32 {
-            const float sv = sp[n];
-#ifdef OCEAN_ABL_NOIN
-            return make_float2(sv, sv);
-#endif
-            const float dv = sm[n];
-            const float tx = (n == 0) ? dv : sv;
-            const float tz = row0 ? dv : sv;
-            const float kx = k1[n];
-            const float d = kx * kx + kz2;
-            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;      // |k| > 1e-5 (.h:135)
-            const float cz = c ? -kz : kz * inv;                   // -kz | uz
-            const float cx = c ? kx : -kx * inv;                   //  kx | -ux
-            return make_float2(cz * tz, cx * tx);
-        };
-        auto out = [&](int q, int c, c32 v, int, int) {
-#ifdef OCEAN_ABL_NOSTORE
-            asm volatile("" ::"v"(v.x), "v"(v.y)); if (q >= 0) return;
-#endif
-            float2* __restrict__ zg = zt + (size_t)c * HF::Z_GROUP;
-            if (q <= N / 2) {
-                zg[q] = v;
-                if (q == 0 || q == N / 2) zg[HF::NUP + q] = v;     // self-mirrored columns: both sides
-            } else {
-                zg[HF::NUP + (N - q)] = v;
-            }
-        };
-        batch_fft<N, 2, T, P>(fbuf, a.tw, tid, in, out);
-        OCEAN_STAMP(2);
-    }
-    // -- batch B: slot 0 = pair 2 (dDx/dx, dDz/dz), slot 1 = height ----------------
-    {
-        auto in = [&](int n, int c) -> c32 {
-            const float sv = sp[n];
-#ifdef OCEAN_ABL_NOIN
-            return make_float2(sv, sv);
-#endif
-            if (c) return make_float2(sv, 0.0f);
-            const float kx = k1[n];
-            const float d = kx * kx + kz2;
-            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;
-            return make_float2(kx * kx * inv * sv, kz2 * inv * sv);
-        };
-        auto out = [&](int q, int c, c32 v, int, int) {
-#ifdef OCEAN_ABL_NOSTORE
-            asm volatile("" ::"v"(v.x), "v"(v.y)); if (q >= 0) return;
-#endif
-            if (c) {
-                if (q <= N / 2) zh[q] = v;                          // real input: other half is the conjugate
-                return;
-            }
-            float2* __restrict__ zg = zt + (size_t)2 * HF::Z_GROUP;
-            if (q <= N / 2) {
-                zg[q] = v;
-                if (q == 0 || q == N / 2) zg[HF::NUP + q] = v;
-            } else {
-                zg[HF::NUP + (N - q)] = v;
-            }
-        };
-        batch_fft<N, 2, T, P>(fbuf, a.tw, tid, in, out);
-        OCEAN_STAMP(3);
-    }
+    if (col0) zpass_transforms<N, T, P, true>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_transforms<N, T, P, false>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
 }
 
-template <int N> constexpr size_t rows_lds_bytes()
+template <int N> constexpr size_t zpass_lds_bytes()
 {
     return sizeof(c32) * fft_lds_elems<N, 2>() + sizeof(float) * 2 * N;
 }
@@ -375,107 +437,83 @@ template <int N>
 __device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, int mf, int u, float eps)
 {
     using HF = Half<N>;
-    if (mf <= N / 2) return zg[(size_t)mf * 2 * HF::NUP + u];
-    const c32 v = zg[((size_t)(N - mf) * 2 + 1) * HF::NUP + u];
+#ifdef OCEAN_ABL_NOLOAD
+    return make_float2(1.0f + mf, 0.5f * u);
+#endif
+    if (mf <= N / 2) return zg[(unsigned)(mf * 2 * HF::NUP + u)];
+    // mirror of the self-mirrored units 0 and N/2 is the unit itself (side 0)
+    const int side = (u == 0 || u == N / 2) ? 0 : 1;
+    const c32 v = zg[(unsigned)(((N - mf) * 2 + side) * HF::NUP + u)];
     return make_float2(eps * v.x, eps * v.y);
 }
 
 // ============================================================================
-// k_cols_b: blockIdx.x < HB  -> HEIGHT workgroup: 2*C columns (C transforms of two
-//                                real columns each), raw signed height + min/max
-//           otherwise        -> NORMAL workgroup: C columns of pairs 1 and 2 ->
-//                                normal map texels (p,u) and mirror (-p,-u)
+// k_xpass_height: 2*C rows of the height per workgroup (C transforms of two real
+// rows each: Y_u + i Y_{u+1}), sign, raw signed height out, global min/max.
 // ============================================================================
 template <int N, int C, int T, class P = Plan<N>>
-__global__ void __launch_bounds__(T) k_cols_b(const FrameArgs a)
+__global__ void __launch_bounds__(T) k_xpass_height(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
-    using LS = LastStage<N, C, T, P>;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    constexpr int HB = HF::NUP / (2 * C);                 // height workgroups
-    constexpr int NB = (HF::NU + C - 1) / C;              // normal workgroups
-    static_assert(HF::NUP % (2 * C) == 0, "height column blocks");
-
-    if (blockIdx.x < HB) {
-        constexpr int NW = (T + 63) / 64;
-        float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
-        const int u0 = blockIdx.x * 2 * C;
-        const float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE;
-        float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
-        float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
-        // Y_u(mf) = Zh(mf,u), mf <= N/2; conj Zh(N-mf,u) above (real, even spectrum);
-        // rows 0 and N/2 are real.  Two columns u, u+1 per transform: Y_u + i Y_{u+1}.
-        auto in = [&](int mf, int c) -> c32 {
-            const int row = mf <= N / 2 ? mf : N - mf;
-            const float4 z = *reinterpret_cast<const float4*>(zh + (size_t)row * HF::NUP + u0 + 2 * c);
-            if (mf == 0 || mf == N / 2) return make_float2(z.x, z.z);
-            if (mf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
-            return make_float2(z.x + z.w, z.z - z.y);
-        };
-        auto out = [&](int p, int c, c32 v, int, int) {
-            const int u = u0 + 2 * c;
-            const float s = ((p + u) & 1) ? -1.0f : 1.0f;              // .cpp:388-390
-            const float ha = s * v.x, hb = -s * v.y;
-            if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
-            if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
-            *reinterpret_cast<float2*>(hraw + hraw_index(N, p, u)) = make_float2(ha, hb);
-        };
-        batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
-        // workgroup reduction -> one atomic pair (.cpp:391-392, 407-411)
+    TwiddleRegs<N, C, T, P> twr;
+    twr.load(a.tw, tid);
+    constexpr int NW = (T + 63) / 64;
+    float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
+    const int u0 = xcd_swizzle(blockIdx.x, HF::NUP / (2 * C)) * 2 * C;
+    const float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE;
+    float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
+    float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
+    // Y_u(nf) = Zh(nf,u), nf <= N/2; conj Zh(N-nf,u) above (real, even spectrum);
+    // entries 0 and N/2 are real.  Two rows u, u+1 per transform: Y_u + i Y_{u+1}.
+    auto in = [&](int nf, int c, int, int) -> c32 {
+        const int row = nf <= N / 2 ? nf : N - nf;
+        const float4 z = *reinterpret_cast<const float4*>(zh + (unsigned)(row * HF::NUP + u0 + 2 * c));
+        if (nf == 0 || nf == N / 2) return make_float2(z.x, z.z);
+        if (nf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
+        return make_float2(z.x + z.w, z.z - z.y);
+    };
+    auto out = [&](int p, int c, c32 v, int, int) {
+        const int u = u0 + 2 * c;
+        const float s = ((p + u) & 1) ? -1.0f : 1.0f;              // .cpp:388-390
+        const float ha = s * v.x, hb = -s * v.y;
+        if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
+        if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
+        *reinterpret_cast<float2*>(hraw + hraw_index(N, p, u)) = make_float2(ha, hb);
+    };
+    batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    // workgroup reduction -> one atomic pair (.cpp:391-392, 407-411)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            vmin = fminf(vmin, __shfl_xor(vmin, o));
-            vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        }
-        if ((tid & 63) == 0) { red[tid >> 6] = vmin; red[NW + (tid >> 6)] = vmax; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < NW; ++w) { vmin = fminf(vmin, red[w]); vmax = fmaxf(vmax, red[NW + w]); }
-            atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
-            atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
-        }
-        return;
+    for (int o = 32; o > 0; o >>= 1) {
+        vmin = fminf(vmin, __shfl_xor(vmin, o));
+        vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     }
-
-    // ---- NORMAL workgroup ------------------------------------------------------------
-    const int u0 = xcd_swizzle(blockIdx.x - HB, NB) * C;
-    const float2* __restrict__ z1 = a.z + (size_t)tile * HF::Z_TILE + HF::Z_GROUP;
-    const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
-    float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
-    c32 held[LS::IT][LS::RL];
-    {
-        auto in = [&](int mf, int c) -> c32 { return load_pair_column<N>(z1, mf, u0 + c, -1.0f); };
-        auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
-        batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
-    }
-    {
-        auto in = [&](int mf, int c) -> c32 { return load_pair_column<N>(z2, mf, u0 + c, 1.0f); };
-        auto out = [&](int p, int c, c32 v, int u, int i) {
-            const int q = u0 + c;
-            if (q > N / 2) return;                                      // padding column
-            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-            // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
-            const float4 o = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
-            nrm[(size_t)p * N + q] = o;
-            if (q != 0 && q != N / 2)                                    // mirror texel: slopes odd, derivatives even
-                nrm[(size_t)((N - p) & (N - 1)) * N + (N - q)] = make_float4(-o.x, -o.y, o.z, o.w);
-        };
-        batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
+    if ((tid & 63) == 0) { red[tid >> 6] = vmin; red[NW + (tid >> 6)] = vmax; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) { vmin = fminf(vmin, red[w]); vmax = fmaxf(vmax, red[NW + w]); }
+        atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
+        atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
     }
 }
 
 // ============================================================================
-// k_cols_disp: C columns of pair 0 + raw height -> displacement map texels (p,u)
-// and mirror (-p,-u).  NormalizeHeights (.cpp:443-455) folded in.
+// k_xpass_maps: C output rows (units u0..u0+C-1) of BOTH maps per workgroup, and
+// their mirror rows.  Three transforms per workgroup (pairs 0, 1, 2); the inputs
+// of the next transform are fetched into registers while the current one runs,
+// and the displacement rows stream out while pairs 1 and 2 are transformed:
+//     load p0, p1 | FFT p0 -> store displacement | load p2 | FFT p1 (held) | FFT p2 -> store normal
+// NormalizeHeights (.cpp:443-455) is folded into the displacement store.
 // ============================================================================
 template <int N, int C, int T, class P = Plan<N>>
-__global__ void __launch_bounds__(T) k_cols_disp(const FrameArgs a)
+__global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
+    using FS = FirstStage<N, C, T, P>;
     using LS = LastStage<N, C, T, P>;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -483,10 +521,31 @@ __global__ void __launch_bounds__(T) k_cols_disp(const FrameArgs a)
     constexpr int NB = (HF::NU + C - 1) / C;
     const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
     const float2* __restrict__ z0 = a.z + (size_t)tile * HF::Z_TILE;
+    const float2* __restrict__ z1 = z0 + HF::Z_GROUP;
+    const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
     float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
+    float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
+    OCEAN_STAMP(0);
+    TwiddleRegs<N, C, T, P> twr;
+    twr.load(a.tw, tid);
 
-    // raw heights of the texels this thread will finish, fetched up front
+    // first-stage inputs of one pair for this thread's work items
+    auto fetch = [&](const float2* __restrict__ zg, float eps, c32 (&dst)[FS::IT][FS::R0]) {
+#pragma unroll
+        for (int u = 0; u < FS::IT; ++u) {
+            const int w = tid + u * T;
+            if (!FS::GUARD || w < FS::ITEMS) {
+                const int c = w % C, j = w / C;
+#pragma unroll
+                for (int i = 0; i < FS::R0; ++i) dst[u][i] = load_pair_column<N>(zg, j + i * FS::STRIDE, u0 + c, eps);
+            }
+        }
+    };
+    c32 xa[FS::IT][FS::R0], xb[FS::IT][FS::R0];
+    fetch(z0, -1.0f, xa);
+    fetch(z1, -1.0f, xb);
+    // raw heights of the texels this thread will finish
     float hv[LS::IT][LS::RL];
 #pragma unroll
     for (int u = 0; u < LS::IT; ++u) {
@@ -502,37 +561,73 @@ __global__ void __launch_bounds__(T) k_cols_disp(const FrameArgs a)
     const float mx = key_float(a.minmax[2 * tile + 1]);
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
     const float lambda = a.lambda[tile];
-    auto in = [&](int mf, int c) -> c32 { return load_pair_column<N>(z0, mf, u0 + c, -1.0f); };
-    auto out = [&](int p, int c, c32 v, int u, int i) {
-        const int q = u0 + c;
-        if (q > N / 2) return;
-        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-        // (sign*lambda)*Re Dx, h/A, (sign*lambda)*Re Dz, 1   (.cpp:394-403)
-        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
-        disp[(size_t)p * N + q] = o;
-        if (q != 0 && q != N / 2)                                        // mirror: Dx, Dz odd, height even
-            disp[(size_t)((N - p) & (N - 1)) * N + (N - q)] = make_float4(-o.x, o.y, -o.z, 1.0f);
-    };
-    batch_fft<N, C, T, P>(fbuf, a.tw, tid, in, out);
+
+    // ---- pair 0 -> displacement map -----------------------------------------------
+    {
+        auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
+        auto out = [&](int p, int c, c32 v, int u, int i) {
+            const int q = u0 + c;
+            if (q > N / 2) return;                                       // padding row
+            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+            // (sign*lambda)*Re Dx, h/A, (sign*lambda)*Re Dz, 1   (.cpp:394-403)
+            const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
+#ifdef OCEAN_ABL_NOSTORE
+            asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z)); if (p >= 0) return;
+#endif
+            disp[(unsigned)(q * N + p)] = o;                             // texel (row q, column p)
+            if (q != 0 && q != N / 2)                                    // mirror: Dx, Dz odd, height even
+                disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, o.y, -o.z, 1.0f);
+        };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    }
+    OCEAN_STAMP(1);
+    fetch(z2, 1.0f, xa);             // pair 2 inputs travel while pair 1 is transformed
+    // ---- pairs 1 and 2 -> normal map -----------------------------------------------
+    c32 held[LS::IT][LS::RL];
+    {
+        auto in = [&](int, int, int u, int i) -> c32 { return xb[u][i]; };
+        auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    }
+    OCEAN_STAMP(2);
+    {
+        auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
+        auto out = [&](int p, int c, c32 v, int u, int i) {
+            const int q = u0 + c;
+            if (q > N / 2) return;
+            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+            // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
+            const float4 o = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
+#ifdef OCEAN_ABL_NOSTORE
+            asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); if (p >= 0) return;
+#endif
+            nrm[(unsigned)(q * N + p)] = o;
+            if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
+                nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, -o.y, o.z, o.w);
+        };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    }
+    OCEAN_STAMP(3);
 }
 
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
-#define OCEAN_GEO(n, tr, pr, cc, tc, pc)                                                        \
+#define OCEAN_GEO(n, tr, pr, ch, th, cc, tc, pc)                                                \
     template <> struct Geo<n> {                                                                \
-        static constexpr int T_ROWS = tr;               /* threads of k_rows               */  \
-        static constexpr int CC = cc, T_C = tc;         /* transforms per column workgroup */  \
-        using PR = pr; using PC = pc;                   /* radix plans                     */  \
+        static constexpr int T_ROWS = tr;               /* threads of k_zpass               */ \
+        static constexpr int CH = ch, T_H = th;         /* k_xpass_height: transforms, threads */ \
+        static constexpr int CC = cc, T_C = tc;         /* k_xpass_maps: rows, threads      */ \
+        using PR = pr; using PC = pc;                   /* radix plans                      */ \
     };
-OCEAN_GEO(16, 64, Plan<16>, 4, 64, Plan<16>)
-OCEAN_GEO(32, 64, Plan<32>, 4, 64, Plan<32>)
-OCEAN_GEO(64, 64, Plan<64>, 4, 64, Plan<64>)
-OCEAN_GEO(128, 64, Plan<128>, 4, 64, Plan<128>)
-OCEAN_GEO(256, 64, Plan<256>, 4, 64, Plan<256>)
-OCEAN_GEO(512, 128, Plan<512>, 4, 256, Plan<512>)
-OCEAN_GEO(1024, 128, Plan<1024>, 4, 256, Plan<1024>)
-OCEAN_GEO(2048, 256, Plan<2048>, 4, 512, Plan<2048>)
-OCEAN_GEO(4096, 512, Plan<4096>, 4, 1024, Plan<4096>)
+OCEAN_GEO(16, 64, Plan<16>, 4, 64, 4, 64, Plan<16>)
+OCEAN_GEO(32, 64, Plan<32>, 4, 64, 4, 64, Plan<32>)
+OCEAN_GEO(64, 64, Plan<64>, 4, 64, 4, 64, Plan<64>)
+OCEAN_GEO(128, 64, Plan<128>, 4, 64, 4, 64, Plan<128>)
+OCEAN_GEO(256, 64, Plan<256>, 4, 64, 4, 64, Plan<256>)
+OCEAN_GEO(512, 128, Plan<512>, 2, 128, 4, 256, Plan<512>)
+OCEAN_GEO(1024, 128, Plan<1024>, 2, 128, 4, 256, Plan<1024>)
+OCEAN_GEO(2048, 256, Plan<2048>, 2, 256, 4, 512, Plan<2048>)
+OCEAN_GEO(4096, 512, Plan<4096>, 2, 512, 2, 512, Plan<4096>)
 #undef OCEAN_GEO
 
 }  // namespace ocean
