@@ -158,12 +158,15 @@ class OceanBatch:
         return xi
 
     def time_frames(self, t0: float, dt: float, warmup: int, frames: int, per_kernel: bool = True):
-        """(ms_total, [ms_rows, ms_height, ms_maps]) measured with HIP events on the context's stream."""
+        """(ms_total, [ms per launch, in kernel_names() order]) measured with HIP events on the launch stream."""
         total = C.c_float()
         k = (C.c_float * 3)()
         _abi.check(self._L.ocean_time_frames(self._h, t0, dt, warmup, frames, C.byref(total),
                                              k if per_kernel else None), "ocean_time_frames")
         return total.value, [k[0], k[1], k[2]] if per_kernel else None
+
+    def kernel_names(self):
+        return [self._L.ocean_kernel_name(self._h, i).decode() for i in range(3)]
 
     @property
     def algorithmic_bytes_per_texel(self) -> int:

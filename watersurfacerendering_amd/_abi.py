@@ -31,7 +31,7 @@ SYMBOLS = [
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_device_maps", "ocean_bind_output",
     "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
-    "ocean_time_frames", "ocean_algorithmic_bytes_per_texel",
+    "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
 ]
 
 
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         "ocean_read_spectrum": (i32, [P, u32, C.c_void_p, C.c_void_p]),
         "ocean_read_xi": (i32, [P, u32, C.c_void_p]),
         "ocean_time_frames": (i32, [P, f32, f32, i32, i32, FP, FP]),
+        "ocean_kernel_name": (C.c_char_p, [P, i32]),
         "ocean_algorithmic_bytes_per_texel": (i32, [P]),
     }
     for name, (res, args) in sig.items():

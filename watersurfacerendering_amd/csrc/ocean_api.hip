@@ -314,6 +314,15 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
 
 // ---------------------------------------------------------------------------------
 // frame launch
+template <int N> static const char* kernel_name_of(int idx)
+{
+    if (idx == 0) return "k_zpass";
+    if (idx == 1) return Geo<N>::MERGED ? "k_xpass_height" : "k_xpass_b";
+    if (idx == 2) return Geo<N>::MERGED ? "k_xpass_maps" : "k_xpass_disp";
+    return nullptr;
+}
+
+
 // ---------------------------------------------------------------------------------
 template <class K>
 static hipError_t allow_lds(K kernel, size_t bytes)
@@ -335,13 +344,19 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
     constexpr size_t lds_rows = zpass_lds_bytes<N>();
     constexpr size_t lds_h = sizeof(c32) * fft_lds_elems<N, CH>() + sizeof(float) * 2 * ((G::T_H + 63) / 64);
     constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
-    static_assert(HF::NUP % (2 * CH) == 0, "height row blocks");
-    constexpr unsigned hb = HF::NUP / (2 * CH), nb = (HF::NU + C - 1) / C;
+    constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
+    static_assert(HF::NUP % (2 * CH) == 0 && HF::NUP % (2 * C) == 0, "height row blocks");
+    constexpr unsigned hb = HF::NUP / (2 * CH), hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
     static bool attr_done = false;
     if (!attr_done) {
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_height<N, CH, G::T_H, typename G::PC>, lds_h)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
+        if constexpr (G::MERGED) {
+            if ((e = allow_lds(k_xpass_height<N, CH, G::T_H, typename G::PC>, lds_h)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
+        } else {
+            if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC>, lds_b)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
+        }
         attr_done = true;
     }
 #ifdef OCEAN_STAMPS
@@ -367,20 +382,24 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
     arm(1);
 #endif
-    hipLaunchKernelGGL((k_xpass_height<N, CH, G::T_H, typename G::PC>), dim3(hb, tiles), dim3(G::T_H), lds_h, st, a);
-    if (marks) (void)hipEventRecord(marks[2], st);
     // the maps are shared by all frames: this frame may only start writing them
     // once the previous frame (other stream) has finished its own
-    if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
+    if constexpr (G::MERGED) {
+        hipLaunchKernelGGL((k_xpass_height<N, CH, G::T_H, typename G::PC>), dim3(hb, tiles), dim3(G::T_H), lds_h, st, a);
+        if (marks) (void)hipEventRecord(marks[2], st);
+        if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
 #ifdef OCEAN_STAMPS
-    arm(2);
+        arm(2);
 #endif
-    {
-        unsigned gd = nb;
+        hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+    } else {
+        if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
+        if (marks) (void)hipEventRecord(marks[2], st);
 #ifdef OCEAN_STAMPS
-        if (const char* ev = getenv("OCEAN_DEBUG_DISP_GRID")) gd = (unsigned)atoi(ev);
+        arm(2);
 #endif
-        hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC>), dim3(gd, tiles), dim3(G::T_C), lds_m, st, a);
+        hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
     }
     if (marks) (void)hipEventRecord(marks[3], st);
     return hipGetLastError();
@@ -639,6 +658,23 @@ int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, siz
     return OCEAN_OK;
 }
 #endif
+
+const char* ocean_kernel_name(const ocean_t* c, int idx)
+{
+    if (!c) return nullptr;
+    switch (c->n) {
+        case 16: return kernel_name_of<16>(idx);
+        case 32: return kernel_name_of<32>(idx);
+        case 64: return kernel_name_of<64>(idx);
+        case 128: return kernel_name_of<128>(idx);
+        case 256: return kernel_name_of<256>(idx);
+        case 512: return kernel_name_of<512>(idx);
+        case 1024: return kernel_name_of<1024>(idx);
+        case 2048: return kernel_name_of<2048>(idx);
+        case 4096: return kernel_name_of<4096>(idx);
+        default: return nullptr;
+    }
+}
 
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {

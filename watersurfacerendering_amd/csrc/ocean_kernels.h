@@ -610,24 +610,157 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
     OCEAN_STAMP(3);
 }
 
+// ============================================================================
+// Split x pass (used where one round of workgroups covers the tile, N <= 2048):
+//   k_xpass_b    blockIdx.x < HB  -> HEIGHT workgroup (as k_xpass_height)
+//                otherwise        -> NORMAL workgroup: pairs 1 and 2 -> normal map
+//   k_xpass_disp pair 0 + raw height -> displacement map (needs the min/max)
+// The height transforms then run beside the normal-map ones instead of alone.
+// ============================================================================
+template <int N, int C, int T, class P = Plan<N>>
+__global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using HF = Half<N>;
+    c32* fbuf = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.y;
+    TwiddleRegs<N, C, T, P> twr;
+    twr.load(a.tw, tid);
+    constexpr int HB = HF::NUP / (2 * C);                 // height workgroups
+    constexpr int NB = (HF::NU + C - 1) / C;              // normal workgroups
+    static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
+
+    if (blockIdx.x < HB) {
+        constexpr int NW = (T + 63) / 64;
+        float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
+        const int u0 = xcd_swizzle(blockIdx.x, HB) * 2 * C;
+        const float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE;
+        float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
+        float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
+        auto in = [&](int nf, int c, int, int) -> c32 {
+            const int row = nf <= N / 2 ? nf : N - nf;
+            const float4 z = *reinterpret_cast<const float4*>(zh + (unsigned)(row * HF::NUP + u0 + 2 * c));
+            if (nf == 0 || nf == N / 2) return make_float2(z.x, z.z);
+            if (nf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
+            return make_float2(z.x + z.w, z.z - z.y);
+        };
+        auto out = [&](int p, int c, c32 v, int, int) {
+            const int u = u0 + 2 * c;
+            const float s = ((p + u) & 1) ? -1.0f : 1.0f;
+            const float ha = s * v.x, hb = -s * v.y;
+            if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
+            if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
+            *reinterpret_cast<float2*>(hraw + hraw_index(N, p, u)) = make_float2(ha, hb);
+        };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            vmin = fminf(vmin, __shfl_xor(vmin, o));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        }
+        if ((tid & 63) == 0) { red[tid >> 6] = vmin; red[NW + (tid >> 6)] = vmax; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) { vmin = fminf(vmin, red[w]); vmax = fmaxf(vmax, red[NW + w]); }
+            atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
+            atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
+        }
+        return;
+    }
+
+    // ---- NORMAL workgroup ------------------------------------------------------------
+    // (writing the two halves of a texel separately -- 8-byte stores, no registers held
+    // between the transforms -- was measured 50% slower: the partial lines do not meet in L2)
+    using LS = LastStage<N, C, T, P>;
+    const int u0 = xcd_swizzle(blockIdx.x - HB, NB) * C;
+    const float2* __restrict__ z1 = a.z + (size_t)tile * HF::Z_TILE + HF::Z_GROUP;
+    const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
+    float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
+    c32 held[LS::IT][LS::RL];
+    {
+        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z1, nf, u0 + c, -1.0f); };
+        auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    }
+    {
+        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z2, nf, u0 + c, 1.0f); };
+        auto out = [&](int p, int c, c32 v, int u, int i) {
+            const int q = u0 + c;
+            if (q > N / 2) return;                                      // padding row
+            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+            // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
+            const float4 o = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
+            nrm[(unsigned)(q * N + p)] = o;
+            if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
+                nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, -o.y, o.z, o.w);
+        };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    }
+}
+
+template <int N, int C, int T, class P = Plan<N>>
+__global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using HF = Half<N>;
+    using LS = LastStage<N, C, T, P>;
+    c32* fbuf = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.y;
+    constexpr int NB = (HF::NU + C - 1) / C;
+    const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
+    const float2* __restrict__ z0 = a.z + (size_t)tile * HF::Z_TILE;
+    const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
+    float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
+    TwiddleRegs<N, C, T, P> twr;
+    twr.load(a.tw, tid);
+    float hv[LS::IT][LS::RL];
+#pragma unroll
+    for (int u = 0; u < LS::IT; ++u) {
+        const int w = tid + u * T;
+        if (!LS::GUARD || w < LS::ITEMS) {
+            const int c = w % C, j = w / C;
+#pragma unroll
+            for (int i = 0; i < LS::RL; ++i) hv[u][i] = hraw[hraw_index(N, j + i * LS::STRIDE, u0 + c)];
+        }
+    }
+    const float mn = key_float(a.minmax[2 * tile + 0]);
+    const float mx = key_float(a.minmax[2 * tile + 1]);
+    const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
+    const float lambda = a.lambda[tile];
+    auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z0, nf, u0 + c, -1.0f); };
+    auto out = [&](int p, int c, c32 v, int u, int i) {
+        const int q = u0 + c;
+        if (q > N / 2) return;
+        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
+        disp[(unsigned)(q * N + p)] = o;
+        if (q != 0 && q != N / 2)
+            disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, o.y, -o.z, 1.0f);
+    };
+    batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+}
+
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
-#define OCEAN_GEO(n, tr, pr, ch, th, cc, tc, pc)                                                \
+#define OCEAN_GEO(n, tr, pr, merged, ch, th, cc, tc, pc)                                        \
     template <> struct Geo<n> {                                                                \
         static constexpr int T_ROWS = tr;               /* threads of k_zpass               */ \
+        static constexpr bool MERGED = merged;          /* x pass: height + maps | b + disp */ \
         static constexpr int CH = ch, T_H = th;         /* k_xpass_height: transforms, threads */ \
-        static constexpr int CC = cc, T_C = tc;         /* k_xpass_maps: rows, threads      */ \
+        static constexpr int CC = cc, T_C = tc;         /* maps / b / disp: rows, threads   */ \
         using PR = pr; using PC = pc;                   /* radix plans                      */ \
     };
-OCEAN_GEO(16, 64, Plan<16>, 4, 64, 4, 64, Plan<16>)
-OCEAN_GEO(32, 64, Plan<32>, 4, 64, 4, 64, Plan<32>)
-OCEAN_GEO(64, 64, Plan<64>, 4, 64, 4, 64, Plan<64>)
-OCEAN_GEO(128, 64, Plan<128>, 4, 64, 4, 64, Plan<128>)
-OCEAN_GEO(256, 64, Plan<256>, 4, 64, 4, 64, Plan<256>)
-OCEAN_GEO(512, 128, Plan<512>, 2, 128, 4, 256, Plan<512>)
-OCEAN_GEO(1024, 128, Plan<1024>, 2, 128, 4, 256, Plan<1024>)
-OCEAN_GEO(2048, 256, Plan<2048>, 2, 256, 4, 512, Plan<2048>)
-OCEAN_GEO(4096, 512, Plan<4096>, 2, 512, 2, 512, Plan<4096>)
+OCEAN_GEO(16, 64, Plan<16>, false, 4, 64, 4, 64, Plan<16>)
+OCEAN_GEO(32, 64, Plan<32>, false, 4, 64, 4, 64, Plan<32>)
+OCEAN_GEO(64, 64, Plan<64>, false, 4, 64, 4, 64, Plan<64>)
+OCEAN_GEO(128, 64, Plan<128>, false, 4, 64, 4, 64, Plan<128>)
+OCEAN_GEO(256, 64, Plan<256>, false, 4, 64, 4, 64, Plan<256>)
+OCEAN_GEO(512, 128, Plan<512>, false, 2, 128, 4, 256, Plan<512>)
+OCEAN_GEO(1024, 128, Plan<1024>, false, 2, 128, 4, 256, Plan<1024>)
+OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, Plan<2048>)
+OCEAN_GEO(4096, 512, Plan<4096>, true, 2, 512, 2, 512, Plan<4096>)
 #undef OCEAN_GEO
 
 }  // namespace ocean
