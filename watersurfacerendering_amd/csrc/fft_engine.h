@@ -122,17 +122,32 @@ template <> struct Dft<16> {
     }
 };
 
-// x[i] *= w1^i, powers built in log depth (<= 4 products deep for R = 16)
+// x[i] *= w1^i.  Powers are built by squaring / pairwise products (at most four
+// products deep for R = 16, ~2.4e-7 relative) and consumed as soon as they exist, so
+// only w1..w(R/2) stay live (not all R-1 powers).
 template <int R>
 __device__ __forceinline__ void apply_twiddles(c32 (&x)[R], c32 w1)
 {
-    c32 pw[R];
-    pw[0] = make_float2(1.f, 0.f);
-    pw[1] = w1;
+    if constexpr (R == 2) {
+        x[1] = cmul(x[1], w1);
+    } else if constexpr (R == 4) {
+        const c32 w2 = cmul(w1, w1);
+        x[1] = cmul(x[1], w1);
+        x[2] = cmul(x[2], w2);
+        x[3] = cmul(x[3], cmul(w1, w2));
+    } else {
+        constexpr int H = R / 2;
+        c32 pw[H + 1];
+        pw[1] = w1;
+        x[1] = cmul(x[1], w1);
 #pragma unroll
-    for (int i = 2; i < R; ++i) pw[i] = cmul(pw[i / 2], pw[i - i / 2]);
+        for (int i = 2; i <= H; ++i) {
+            pw[i] = cmul(pw[i / 2], pw[i - i / 2]);
+            x[i] = cmul(x[i], pw[i]);
+        }
 #pragma unroll
-    for (int i = 1; i < R; ++i) x[i] = cmul(x[i], pw[i]);
+        for (int i = 1; i < H; ++i) x[H + i] = cmul(x[H + i], cmul(pw[H], pw[i]));
+    }
 }
 
 // ---- radix plans -------------------------------------------------------------

@@ -36,6 +36,25 @@
 
 namespace ocean {
 
+typedef float ocean_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(float4* p, float4 v)
+{
+    ocean_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<ocean_f4*>(p));
+}
+// Map stores: plain where the maps still fit the 256 MiB Infinity Cache beside the
+// intermediates (N <= 2048, measured 2-4 % faster), non-temporal above (4096: +10 %).
+template <int N> __device__ __forceinline__ void store_map(float4* p, float4 v)
+{
+#ifdef OCEAN_NT_STORES
+    store_nt(p, v);
+#else
+    if constexpr (N >= 4096) store_nt(p, v);
+    else *p = v;
+#endif
+}
+#define OCEAN_STORE(ptr, val) store_map<N>((ptr), (val))
+
 struct TileParams {          // device copy of one tile's properties
     float wind_x, wind_y;    // unit vector (SetWindDirection, .cpp:476-479)
     float wind_speed;        // (.cpp:481-484)
@@ -367,7 +386,10 @@ __global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass
     {
         constexpr int ELEMS = N;                      // 2 columns * N/2 element pairs
         constexpr int P1 = (ELEMS + T - 1) / T;
-        constexpr int PB = P1 > 4 ? 4 : P1;
+#ifndef OCEAN_PB
+#define OCEAN_PB 4
+#endif
+        constexpr int PB = P1 > OCEAN_PB ? OCEAN_PB : P1;
         static_assert(P1 % PB == 0, "phase-1 batches");
 #pragma unroll 1
         for (int ub = 0; ub < P1; ub += PB) {
@@ -574,9 +596,9 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z)); if (p >= 0) return;
 #endif
-            disp[(unsigned)(q * N + p)] = o;                             // texel (row q, column p)
+            OCEAN_STORE(&disp[(unsigned)(q * N + p)], o);                             // texel (row q, column p)
             if (q != 0 && q != N / 2)                                    // mirror: Dx, Dz odd, height even
-                disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, o.y, -o.z, 1.0f);
+                OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
         };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
@@ -601,9 +623,9 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); if (p >= 0) return;
 #endif
-            nrm[(unsigned)(q * N + p)] = o;
+            OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
             if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-                nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, -o.y, o.z, o.w);
+                OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
         };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
@@ -617,8 +639,11 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 //   k_xpass_disp pair 0 + raw height -> displacement map (needs the min/max)
 // The height transforms then run beside the normal-map ones instead of alone.
 // ============================================================================
+#ifndef OCEAN_XB_MINW
+#define OCEAN_XB_MINW 1
+#endif
 template <int N, int C, int T, class P = Plan<N>>
-__global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
+__global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
@@ -683,6 +708,9 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
+    // keep the second transform's loads from being hoisted over the first one's last
+    // stage: that costs ~45 VGPRs and with them the second workgroup per CU
+    __builtin_amdgcn_sched_barrier(0);
     {
         auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z2, nf, u0 + c, 1.0f); };
         auto out = [&](int p, int c, c32 v, int u, int i) {
@@ -691,16 +719,19 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             const float s = ((p + q) & 1) ? -1.0f : 1.0f;
             // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
             const float4 o = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
-            nrm[(unsigned)(q * N + p)] = o;
+            OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
             if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-                nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, -o.y, o.z, o.w);
+                OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
         };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
 }
 
+#ifndef OCEAN_XD_MINW
+#define OCEAN_XD_MINW 1
+#endif
 template <int N, int C, int T, class P = Plan<N>>
-__global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
+__global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
@@ -735,9 +766,9 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
         if (q > N / 2) return;
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
         const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
-        disp[(unsigned)(q * N + p)] = o;
+        OCEAN_STORE(&disp[(unsigned)(q * N + p)], o);
         if (q != 0 && q != N / 2)
-            disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))] = make_float4(-o.x, o.y, -o.z, 1.0f);
+            OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
     };
     batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 }
