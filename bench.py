@@ -86,8 +86,10 @@ def cpu_baseline(n: int, budget_s: float):
     }
 
 
-def measure_config(W, n, tiles, device, steps, warmup):
+def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32):
     b = W.OceanBatch(n, tiles, device)
+    if h0_bits != 32:
+        b.set_spectrum_precision(h0_bits)
     b.prepare(SEED)
     ms, kern = b.time_frames(0.0, DT, warmup, steps, per_kernel=True)
     per = ms / steps * 1e-3
@@ -123,9 +125,9 @@ def main():
     first_tile, _ = wdist.tile_shard(tiles * world, world, rank)
     b = W.OceanBatch(n, tiles, local_rank)
     # maps live in a torch tensor so the gather leg can send them without a copy
-    maps = torch.empty((tiles, 2, n, n, 4), dtype=torch.float32, device=dev)
-    if tiles == 1:
-        b.bind_output(maps[0, 0].data_ptr(), maps[0, 1].data_ptr())
+    # layout [2 (displacement, normal)][tiles][N][N][4] = the library's own tile-major map arrays
+    maps = torch.empty((2, tiles, n, n, 4), dtype=torch.float32, device=dev)
+    b.bind_output(maps[0].data_ptr(), maps[1].data_ptr())
     b.prepare(SEED + first_tile)
 
     def barrier():
@@ -180,7 +182,7 @@ def main():
 
     # ---- RCCL gather of the packed maps (north-star exchange step), outside the timed region
     gather = None
-    if world > 1 and not args.no_gather and tiles == 1:
+    if world > 1 and not args.no_gather:
         reps = 10
         sync(); barrier()
         tg = time.perf_counter()
@@ -201,9 +203,12 @@ def main():
             b.close()
             del maps
             torch.cuda.empty_cache()
+            # BASELINE.json configs beside the headline one (parity for all of them: tests/test_parity_gpu.py)
             extra["512x512_single_tile"] = measure_config(W, 512, 1, local_rank, 300, 20)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
-            extra["1024x1024_batch8"] = measure_config(W, 1024, 8, local_rank, 50, 5)
+            extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)
+            extra["4096x4096_fp32_spectrum"] = measure_config(W, 4096, 1, local_rank, 30, 5)
+            extra["4096x4096_fp16_spectrum"] = measure_config(W, 4096, 1, local_rank, 30, 5, h0_bits=16)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(n, args.cpu_seconds)

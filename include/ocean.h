@@ -130,11 +130,17 @@ int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
  * internal buffers.                                                              */
 int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
 
-/* Frame pipelining.  By default (depth 2) consecutive asynchronous frames
+/* Spectrum storage precision: 32 (default) or 16.  With 16 the per-frame passes read a
+ * half2 copy of h0(k), scaled per tile by a power of two, instead of the fp32 one
+ * (8 instead of 12 bytes per texel of input; omega stays fp32).  Takes effect at the
+ * next ocean_prepare.  Accuracy: tests/test_parity_gpu.py states the measured bound.   */
+int ocean_set_spectrum_precision(ocean_t* ctx, int bits);
+
+/* Frame pipelining.  With depth 2 consecutive asynchronous frames
  * alternate between two sets of intermediate buffers on two internal streams:
  * the row pass of frame f+1 overlaps the column passes of frame f, the maps are
  * still written strictly in frame order, and ocean_synchronize / every
- * synchronous call drains both.  depth 1 = everything on one stream.  (The
+ * synchronous call drains both.  depth 1 (the default) = everything on one stream.  (The
  * reference is strictly serial; its own DOUBLE_BUFFERED switch,
  * WaterSurfaceMesh.h:34, is the same idea on the upload side.)                   */
 int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 or 2 */);

@@ -295,3 +295,52 @@ def test_cpp_adaptor_matches_python_binding(tmp_path):
     assert float(sd) == pytest.approx(float(np.sum(d[0].astype(np.float64).ravel() * w7)), rel=1e-9, abs=1e-6)
     assert float(sn) == pytest.approx(float(np.sum(q[0].astype(np.float64).ravel() * w5)), rel=1e-9, abs=1e-6)
     b.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 4: fp16 spectrum vs fp32 spectrum, both against the float64-FFT oracle
+FP16_TOL = 1e-3      # stated tolerance for the half2 spectrum: max|err| <= 1e-3 * max|channel| (measured ~2e-4)
+
+
+@pytest.mark.parametrize("n", [512, 4096])
+def test_fp16_spectrum_within_stated_tolerance(n):
+    from oracle import oracle as O
+    import watersurfacerendering_amd as W
+    seed = 0x5EED0000
+    b = W.OceanBatch(n, 1, 0)
+    b.set_spectrum_precision(16)
+    b.prepare(seed)
+    xi = b.read_xi(0)
+    o = make_oracle(n, xi)
+    t = 4.5
+    ao, do, no = o.compute_waves(t, fft=O.FFT_F64)
+    a16 = float(b.compute_waves(t)[0])
+    d16, n16 = b.read_maps()
+    e16 = max(chan_err(d16[0], do)[:3] + chan_err(n16[0], no))
+    assert abs(a16 - ao) <= FP16_TOL * ao
+    assert e16 <= FP16_TOL, e16
+    assert e16 > TOL / 10          # it really is the reduced-precision path
+    b.set_spectrum_precision(32)
+    with pytest.raises(W.OceanError):
+        b.compute_waves(t)          # precision change needs Prepare(), like every spectrum parameter
+    b.prepare(seed)
+    a32 = float(b.compute_waves(t)[0])
+    d32, n32 = b.read_maps()
+    assert max(chan_err(d32[0], do) + chan_err(n32[0], no)) <= TOL
+    assert abs(a32 - ao) <= TOL_AMP * ao
+    b.close()
+
+
+def test_pipeline_depth_two_gives_identical_frames():
+    import watersurfacerendering_amd as W
+    n = 512
+    ref = W.OceanBatch(n, 1, 0); ref.prepare(21)
+    pip = W.OceanBatch(n, 1, 0); pip.prepare(21); pip.set_pipeline_depth(2)
+    for j in range(5):
+        ref.compute_waves_async(0.3 * j)
+        pip.compute_waves_async(0.3 * j)
+    ref.synchronize(); pip.synchronize()
+    d1, q1 = ref.read_maps(); d2, q2 = pip.read_maps()
+    assert np.array_equal(d1, d2) and np.array_equal(q1, q2)
+    assert ref.heights(0) == pip.heights(0)
+    ref.close(); pip.close()

@@ -30,7 +30,7 @@ SYMBOLS = [
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_device_maps", "ocean_bind_output",
-    "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
+    "ocean_set_spectrum_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
     "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
 ]
 
@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
         "ocean_read_maps": (i32, [P, u32, u32, C.c_void_p, C.c_void_p]),
         "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
         "ocean_bind_output": (i32, [P, P, P]),
+        "ocean_set_spectrum_precision": (i32, [P, i32]),
         "ocean_set_pipeline_depth": (i32, [P, i32]),
         "ocean_stream": (P, [P]),
         "ocean_set_stream": (i32, [P, P]),

@@ -63,6 +63,10 @@ struct ocean_ctx {
     float* lambda = nullptr;
     TileParams* tparams = nullptr;
     float2* xi = nullptr;          // injected or generated draws (kept for read-back)
+    int h0_bits = 32;              // 32, or 16: frames read a scaled half2 copy of h0
+    __half2* h0h = nullptr;
+    float* h0_inv_scale = nullptr;
+    unsigned* h0_maxbits = nullptr;
     unsigned* h_minmax = nullptr;  // pinned
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t ev[8] = {};
@@ -71,12 +75,14 @@ struct ocean_ctx {
 static void free_device(ocean_ctx* c)
 {
     void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->z[0], c->z[1], c->zh[0], c->zh[1], c->hraw[0], c->hraw[1],
-                    c->minmax[0], c->minmax[1], c->disp, c->nrm, c->toff, c->lambda, c->tparams, c->xi};
+                    c->minmax[0], c->minmax[1], c->disp, c->nrm, c->toff, c->lambda, c->tparams, c->xi,
+                    c->h0h, c->h0_inv_scale, c->h0_maxbits};
     for (void* b : bufs) if (b) (void)hipFree(b);
     c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr;
     for (int i = 0; i < 2; ++i) { c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr; }
     c->disp = nullptr; c->nrm = nullptr; c->toff = nullptr;
     c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
+    c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr;
     c->prepared = false;
     c->done_valid[0] = c->done_valid[1] = false;
 }
@@ -304,6 +310,19 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
                            c->k1d, c->tparams, (int)n);
     }
     HIP_TRY(hipGetLastError());
+    if (c->h0_bits == 16) {
+        if (!c->h0h) {
+            HIP_TRY(hipMalloc(&c->h0h, t * n2 * sizeof(__half2)));
+            HIP_TRY(hipMalloc(&c->h0_inv_scale, t * sizeof(float)));
+            HIP_TRY(hipMalloc(&c->h0_maxbits, t * sizeof(unsigned)));
+        }
+        HIP_TRY(hipMemsetAsync(c->h0_maxbits, 0, t * sizeof(unsigned), stream_of(c, 0)));
+        dim3 gh(1024, (unsigned)t);
+        hipLaunchKernelGGL(k_h0_absmax, gh, dim3(256), 0, stream_of(c, 0), c->h0, c->h0_maxbits, n2);
+        hipLaunchKernelGGL(k_h0_to_half, gh, dim3(256), 0, stream_of(c, 0), c->h0, c->h0h, c->h0_maxbits,
+                           c->h0_inv_scale, n2);
+        HIP_TRY(hipGetLastError());
+    }
     SYNC_ALL(c);
     c->seed = seed;
     c->prepared = true;
@@ -350,6 +369,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
     static bool attr_done = false;
     if (!attr_done) {
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true>, lds_rows)) != hipSuccess) return e;
         if constexpr (G::MERGED) {
             if ((e = allow_lds(k_xpass_height<N, CH, G::T_H, typename G::PC>, lds_h)) != hipSuccess) return e;
             if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
@@ -375,7 +395,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
 #ifdef OCEAN_STAMPS
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
-        hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows, st, a);
+        if (a.h0h)
+            hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, true>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows, st, a);
+        else
+            hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows, st, a);
     }
     if (marks) (void)hipEventRecord(marks[1], st);
 #ifdef OCEAN_STAMPS
@@ -417,6 +440,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     if (pipe && c->done_valid[1 - set]) wait = c->done[1 - set];
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
+    a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.disp = c->ext_disp ? c->ext_disp : c->disp;
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrm;
@@ -593,6 +617,14 @@ int ocean_read_xi(ocean_t* c, uint32_t tile, float* xi)
     const size_t n2 = (size_t)c->n * c->n;
     SYNC_ALL(c);
     HIP_TRY(hipMemcpy(xi, c->xi + tile * n2, n2 * sizeof(float2), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int ocean_set_spectrum_precision(ocean_t* c, int bits)
+{
+    if (!c || (bits != 16 && bits != 32)) return OCEAN_E_INVALID;
+    if (bits != c->h0_bits) c->prepared = false;     // the copy is built by ocean_prepare
+    c->h0_bits = bits;
     return OCEAN_OK;
 }
 

@@ -31,6 +31,7 @@
 // roofline accounting of SURVEY.md section 8d assumes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "fft_engine.h"
 
@@ -69,6 +70,8 @@ struct TileParams {          // device copy of one tile's properties
 struct FrameArgs {
     const float2* h0;        // [tiles][N][N]   base amplitudes h0(k), TRANSPOSED: [n (kx index)][m (kz index)]
     const float* omega;      // [tiles][N][N]   quantised dispersion, same layout
+    const __half2* h0h;      // [tiles][N][N]   optional fp16 copy of h0 scaled by 1/h0_inv_scale[tile] (null = fp32)
+    const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
     const float2* tw;        // [N]             exp(+2 pi i k / N)
     float2* z;               // [tiles][3][N/2+1][2][NUP] row-transformed pairs: row m, side 0 = columns
@@ -181,6 +184,37 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
     }
     h0[tile * n2 + i] = a;
     omega[tile * n2 + i] = w;
+}
+
+// fp16 spectrum variant (BASELINE config 4): h0 stored as half2 scaled per tile so
+// that max|component| maps to 2^14 (keeps the small amplitudes normal numbers).
+__global__ void k_h0_absmax(const float2* __restrict__ h0, unsigned* __restrict__ maxbits, size_t n2)
+{
+    const int tile = blockIdx.y;
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = h0[tile * n2 + i];
+        m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits + tile, __float_as_uint(m));   // non-negative floats order like uints
+}
+
+__global__ void k_h0_to_half(const float2* __restrict__ h0, __half2* __restrict__ h0h, const unsigned* __restrict__ maxbits,
+                             float* __restrict__ inv_scale, size_t n2)
+{
+    const int tile = blockIdx.y;
+    const float m = __uint_as_float(maxbits[tile]);
+    // power-of-two scale: exact to apply and to undo
+    int e = 0;
+    if (m > 0.0f) (void)frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+    const float scale = ldexpf(1.0f, 14 - e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[tile] = ldexpf(1.0f, e - 14);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = h0[tile * n2 + i];
+        h0h[tile * n2 + i] = __floats2half2_rn(v.x * scale, v.y * scale);
+    }
 }
 
 // ============================================================================
@@ -358,7 +392,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifndef OCEAN_ZPASS_MINW
 #define OCEAN_ZPASS_MINW 1
 #endif
-template <int N, int T, class P = Plan<N>>
+template <int N, int T, class P = Plan<N>, bool H16 = false>
 __global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -378,6 +412,7 @@ __global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;               // [N], cache-resident table
     const bool col0 = (nb == 0);
+    [[maybe_unused]] const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
 
     OCEAN_STAMP(0);
     TwiddleRegs<N, 2, T, P> twr;
@@ -405,7 +440,15 @@ __global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass
 #ifdef OCEAN_ABL_NOLOAD
                     hv[u] = make_float4(1.f + g, 2.f, 3.f, 4.f); wv[u] = make_float2(0.5f, 0.25f);
 #else
-                    hv[u] = *reinterpret_cast<const float4*>(h0 + g);
+                    if constexpr (H16) {
+                        const float2 raw2 = *reinterpret_cast<const float2*>(a.h0h + tile * n2 + g);   // two half2
+                        const __half2 ha = *reinterpret_cast<const __half2*>(&raw2.x);
+                        const __half2 hb = *reinterpret_cast<const __half2*>(&raw2.y);
+                        const float2 fa = __half22float2(ha), fb = __half22float2(hb);
+                        hv[u] = make_float4(fa.x * h16s, fa.y * h16s, fb.x * h16s, fb.y * h16s);
+                    } else {
+                        hv[u] = *reinterpret_cast<const float4*>(h0 + g);
+                    }
                     wv[u] = *reinterpret_cast<const float2*>(om + g);
 #endif
                 }
