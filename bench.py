@@ -11,6 +11,14 @@ with seed 0x5EED0000 + tile_index, t_j = 0.05*j.  Inputs
 omega) are resident in HBM before the timed region; outputs are the two finished
 RGBA32F maps in HBM (D2H read-back is not part of the metric).
 
+The K timed steps are K asynchronous ocean_compute_waves_async calls followed by one
+synchronise.  With --depth 2 (default) consecutive frames alternate between two
+independent chains (own stream, own intermediates, own map set), so one frame's first
+pass overlaps the other's map passes; every frame is still computed in full and its
+maps stay addressable until the chain is reused.  --depth 1 = strictly serial frames
+(also reported under extra).  Per-launch durations for the roofline object are always
+measured serially (HIP events around each launch, one frame at a time).
+
 Multi-GPU: tiles are independent, so every rank synthesises its own tile(s)
 with no data-path collective ("weak" scaling, value = frames of all ranks per
 second).  The north-star's single RCCL gather of the packed maps is measured
@@ -50,6 +58,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=2048, help="tile size N (default: the roofline config, 2048)")
     ap.add_argument("--tiles", type=int, default=1, help="independent tiles per rank per step")
+    ap.add_argument("--depth", type=int, default=2, help="frame pipeline depth of the asynchronous API (1 = strictly serial frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather measurement at N>1")
@@ -86,16 +95,17 @@ def cpu_baseline(n: int, budget_s: float):
     }
 
 
-def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32):
+def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1):
     b = W.OceanBatch(n, tiles, device)
     if h0_bits != 32:
         b.set_spectrum_precision(h0_bits)
+    b.set_pipeline_depth(depth)
     b.prepare(SEED)
     ms, kern = b.time_frames(0.0, DT, warmup, steps, per_kernel=True)
     per = ms / steps * 1e-3
     KERNEL_ORDER = b.kernel_names()
     b.close()
-    return {"size": n, "tiles_per_step": tiles, "frames_per_s": tiles / per, "us_per_step": per * 1e6,
+    return {"size": n, "tiles_per_step": tiles, "pipeline_depth": depth, "frames_per_s": tiles / per, "us_per_step": per * 1e6,
             "gtexels_per_s": n * n * tiles / per * 1e-9, "algorithmic_GBps": FRAME_BYTES_SURVEY * n * n * tiles / per * 1e-9,
             "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern)}}
 
@@ -124,10 +134,7 @@ def main():
     n, tiles = args.size, args.tiles
     first_tile, _ = wdist.tile_shard(tiles * world, world, rank)
     b = W.OceanBatch(n, tiles, local_rank)
-    # maps live in a torch tensor so the gather leg can send them without a copy
-    # layout [2 (displacement, normal)][tiles][N][N][4] = the library's own tile-major map arrays
-    maps = torch.empty((2, tiles, n, n, 4), dtype=torch.float32, device=dev)
-    b.bind_output(maps[0].data_ptr(), maps[1].data_ptr())
+    b.set_pipeline_depth(args.depth)
     b.prepare(SEED + first_tile)
 
     def barrier():
@@ -151,7 +158,8 @@ def main():
     frames_per_s = world * tiles * args.steps / elapsed
 
     # ---- dominant-kernel roofline, measured live with HIP events on the launch stream
-    _, kern_ms = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
+    # (time_frames' per-kernel pass runs one frame at a time on one stream: serial launch durations)
+    ms_serial, kern_ms = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
     KERNEL_ORDER = b.kernel_names()
     dom = max(range(3), key=lambda i: kern_ms[i])
     dom_name = KERNEL_ORDER[dom]
@@ -172,6 +180,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_us": kern_ms[dom] * 1e3,
+                "launch_us_mode": "one frame at a time on one stream (HIP events around each launch)",
                 "bytes_model": "SURVEY.md 8d (108 B/texel per frame) apportioned per launch",
                 "achieved_on_this_pipelines_own_bytes": dom_bytes_actual / (kern_ms[dom] * 1e-3) * 1e-9,
                 "own_bytes_per_launch": dom_bytes_actual,
@@ -184,6 +193,10 @@ def main():
     gather = None
     if world > 1 and not args.no_gather:
         reps = 10
+        # layout [2 (displacement, normal)][tiles][N][N][4] = the library's own tile-major map arrays;
+        # binding caller-owned output makes the frames strictly serial (one map set)
+        maps = torch.empty((2, tiles, n, n, 4), dtype=torch.float32, device=dev)
+        b.bind_output(maps[0].data_ptr(), maps[1].data_ptr())
         sync(); barrier()
         tg = time.perf_counter()
         for j in range(reps):
@@ -201,14 +214,16 @@ def main():
         extra = {}
         if not args.no_extra and world == 1:
             b.close()
-            del maps
             torch.cuda.empty_cache()
+            # strictly serial frames (what a caller of the synchronous ComputeWaves sees, minus the read-back)
+            extra["2048x2048_serial_frames_depth1"] = measure_config(W, n, tiles, local_rank, 100, 10, depth=1)
             # BASELINE.json configs beside the headline one (parity for all of them: tests/test_parity_gpu.py)
-            extra["512x512_single_tile"] = measure_config(W, 512, 1, local_rank, 300, 20)
+            extra["512x512_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20)
+            extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 300, 20, depth=4)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)
-            extra["4096x4096_fp32_spectrum"] = measure_config(W, 4096, 1, local_rank, 30, 5)
-            extra["4096x4096_fp16_spectrum"] = measure_config(W, 4096, 1, local_rank, 30, 5, h0_bits=16)
+            extra["4096x4096_fp32_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 30, 6, depth=2)
+            extra["4096x4096_fp16_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 30, 6, h0_bits=16, depth=2)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(n, args.cpu_seconds)
@@ -220,6 +235,9 @@ def main():
             "config": {"workload": f"{n}x{n} tile, FULL7 (7 real fields via 3.5 complex 2-D iFFTs), "
                                    f"{tiles} tile(s) per rank per step, reference default parameters",
                        "tile_size": n, "tiles_per_rank": tiles, "seed": SEED, "dt": DT,
+                       "pipeline_depth": args.depth,
+                       "api": "ocean_compute_waves_async x steps, then ocean_synchronize (frames alternate between "
+                              f"{args.depth} independent chains, each with its own intermediates and map set)",
                        "parallelism": f"tiles sharded 1 process per GPU x{world}, no data-path collective"},
             "gtexels_per_s": n * n * frames_per_s * 1e-9,
             "roofline": roofline,

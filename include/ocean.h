@@ -136,13 +136,14 @@ int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
  * next ocean_prepare.  Accuracy: tests/test_parity_gpu.py states the measured bound.   */
 int ocean_set_spectrum_precision(ocean_t* ctx, int bits);
 
-/* Frame pipelining.  With depth 2 consecutive asynchronous frames
- * alternate between two sets of intermediate buffers on two internal streams:
- * the row pass of frame f+1 overlaps the column passes of frame f, the maps are
- * still written strictly in frame order, and ocean_synchronize / every
- * synchronous call drains both.  depth 1 (the default) = everything on one stream.  (The
- * reference is strictly serial; its own DOUBLE_BUFFERED switch,
- * WaterSurfaceMesh.h:34, is the same idea on the upload side.)                   */
+/* Frame pipelining.  With depth 2 consecutive asynchronous frames alternate between
+ * two independent chains (own stream, own intermediates, own internal map set): the
+ * first pass of one frame fills the memory-idle phases of the other frame's map
+ * passes.  ocean_synchronize and every synchronous call drain both; the read-out
+ * functions and ocean_device_maps then refer to the frame enqueued last.  Caller-bound
+ * output buffers (ocean_bind_output) or a caller stream force depth 1.  depth 1 (the
+ * default) = everything on one stream.  (The reference is strictly serial; its own
+ * DOUBLE_BUFFERED switch, WaterSurfaceMesh.h:34, is the same idea on the upload side.)  */
 int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 or 2 */);
 
 /* The hipStream_t the most recent frame was enqueued on (as void*), and a way

@@ -27,6 +27,8 @@ static thread_local int g_last_hip = 0;
         }                                               \
     } while (0)
 
+static constexpr int MAXD = 4;     // maximum pipeline depth (independent frame chains)
+
 struct ocean_ctx {
     uint32_t n = 0;
     uint32_t tiles = 0;
@@ -36,13 +38,12 @@ struct ocean_ctx {
     // stream, so the row pass of frame f+1 overlaps the column passes of frame f
     // (pipeline depth 2).  Map writes stay in frame order (event chain).  A
     // caller-supplied stream, or depth 1, runs everything on one stream / set 0.
-    hipStream_t own[2] = {nullptr, nullptr};
+    hipStream_t own[MAXD] = {};
     hipStream_t user = nullptr;
     int depth = 1;
     uint64_t frame_ctr = 0;
     int last_set = 0;
-    hipEvent_t done[2] = {nullptr, nullptr};
-    bool done_valid[2] = {false, false};
+
     std::vector<ocean_params> params;
     uint64_t seed = 0;
     // device state
@@ -50,12 +51,12 @@ struct ocean_ctx {
     float* omega = nullptr;
     float* k1d = nullptr;
     float2* tw = nullptr;
-    float2* z[2] = {nullptr, nullptr};
-    float2* zh[2] = {nullptr, nullptr};
-    float* hraw[2] = {nullptr, nullptr};
-    unsigned* minmax[2] = {nullptr, nullptr};
-    float4* disp = nullptr;
-    float4* nrm = nullptr;
+    float2* z[MAXD] = {};
+    float2* zh[MAXD] = {};
+    float* hraw[MAXD] = {};
+    unsigned* minmax[MAXD] = {};
+    float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
+    float4* nrmN[MAXD] = {};
     float4* ext_disp = nullptr;
     float4* ext_nrm = nullptr;
     float* toff = nullptr;
@@ -70,21 +71,43 @@ struct ocean_ctx {
     unsigned* h_minmax = nullptr;  // pinned
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t ev[8] = {};
+    hipEvent_t end_ev[MAXD] = {};
 };
 
 static void free_device(ocean_ctx* c)
 {
-    void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->z[0], c->z[1], c->zh[0], c->zh[1], c->hraw[0], c->hraw[1],
-                    c->minmax[0], c->minmax[1], c->disp, c->nrm, c->toff, c->lambda, c->tparams, c->xi,
+    void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->toff, c->lambda, c->tparams, c->xi,
                     c->h0h, c->h0_inv_scale, c->h0_maxbits};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int i = 0; i < MAXD; ++i) {
+        void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
+        for (void* b : per) if (b) (void)hipFree(b);
+        c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr;
+        c->dispN[i] = nullptr; c->nrmN[i] = nullptr;
+    }
     c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr;
-    for (int i = 0; i < 2; ++i) { c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr; }
-    c->disp = nullptr; c->nrm = nullptr; c->toff = nullptr;
-    c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
+    c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
     c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr;
     c->prepared = false;
-    c->done_valid[0] = c->done_valid[1] = false;
+}
+
+// intermediates + maps of one pipeline chain (allocated on first use)
+static int alloc_set(ocean_ctx* c, int i)
+{
+    if (c->z[i]) return OCEAN_OK;
+    const size_t n = c->n, n2 = n * n, t = c->tiles;
+    const size_t nu = n / 2 + 1, nup = n / 2 + 8;
+    // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
+    HIP_TRY(hipMalloc(&c->z[i], t * 3 * nu * 2 * nup * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->hraw[i], t * nup * n * sizeof(float)));
+    HIP_TRY(hipMemset(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2)));
+    HIP_TRY(hipMemset(c->zh[i], 0, t * nu * nup * sizeof(float2)));
+    HIP_TRY(hipMemset(c->hraw[i], 0, t * nup * n * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&c->dispN[i], t * n2 * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->nrmN[i], t * n2 * sizeof(float4)));
+    return OCEAN_OK;
 }
 
 static bool size_ok(uint32_t n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
@@ -97,19 +120,10 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMalloc(&c->omega, t * n2 * sizeof(float)));
     HIP_TRY(hipMalloc(&c->k1d, t * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->tw, n * sizeof(float2)));
-    // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
-    const size_t nu = n / 2 + 1, nup = n / 2 + 8;
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc(&c->z[i], t * 3 * nu * 2 * nup * sizeof(float2)));
-        HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
-        HIP_TRY(hipMalloc(&c->hraw[i], t * nup * n * sizeof(float)));
-        HIP_TRY(hipMemset(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2)));
-        HIP_TRY(hipMemset(c->zh[i], 0, t * nu * nup * sizeof(float2)));
-        HIP_TRY(hipMemset(c->hraw[i], 0, t * nup * n * sizeof(float)));
-        HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
+    {
+        int rc_ = alloc_set(c, 0);
+        if (rc_) return rc_;
     }
-    HIP_TRY(hipMalloc(&c->disp, t * n2 * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->nrm, t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->toff, t * sizeof(float)));
     HIP_TRY(hipMalloc(&c->lambda, t * sizeof(float)));
     HIP_TRY(hipMalloc(&c->tparams, t * sizeof(TileParams)));
@@ -128,7 +142,7 @@ static hipStream_t stream_of(const ocean_ctx* c, int set) { return c->user ? c->
 
 static int sync_all(ocean_ctx* c)
 {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) HIP_TRY(hipStreamSynchronize(c->own[i]));
     if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
     return OCEAN_OK;
@@ -186,13 +200,12 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
     int rc = OCEAN_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = OCEAN_E_HIP; break; }
-        for (int i = 0; i < 2 && !rc; ++i) {
+        for (int i = 0; i < MAXD && !rc; ++i)
             if (hipStreamCreateWithFlags(&c->own[i], hipStreamNonBlocking) != hipSuccess) rc = OCEAN_E_HIP;
-            else if (hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) != hipSuccess) rc = OCEAN_E_HIP;
-        }
         if (rc) break;
         if (hipHostMalloc((void**)&c->h_minmax, tiles * 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
+        for (auto& e : c->end_ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         if (rc) break;
         rc = alloc_device(c);
     } while (0);
@@ -209,10 +222,9 @@ void ocean_destroy(ocean_t* c)
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) {
-        if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+    for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) (void)hipStreamDestroy(c->own[i]);
-    }
     delete c;
 }
 
@@ -433,17 +445,28 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
 {
     if (!c) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
-    const bool pipe = pipelined && c->depth == 2 && !c->user;
-    const int set = pipe ? (int)(c->frame_ctr & 1) : c->last_set;
+    // depth D: frames f, f+1, ... run as D independent chains (own stream, own
+    // intermediates, own map set) with no cross-stream dependency at all -- the first
+    // pass of one frame fills the memory-idle phases of the others' map passes.
+    // Caller-bound output buffers or a caller stream force depth 1.
+    const bool pipe = pipelined && c->depth > 1 && !c->user && !c->ext_disp && !c->ext_nrm;
+    if (!pipe && c->depth > 1 && pipelined) {           // leaving pipelined mode: drain the other chains first
+        int rc_ = sync_all(c);
+        if (rc_) return rc_;
+    }
+    const int set = pipe ? (int)(c->frame_ctr % (uint64_t)c->depth) : 0;
+    {
+        int rc_ = alloc_set(c, set);
+        if (rc_) return rc_;
+    }
     hipStream_t st = stream_of(c, set);
     hipEvent_t wait = nullptr;
-    if (pipe && c->done_valid[1 - set]) wait = c->done[1 - set];
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
-    a.disp = c->ext_disp ? c->ext_disp : c->disp;
-    a.nrm = c->ext_nrm ? c->ext_nrm : c->nrm;
+    a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
+    a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
     a.toff = c->use_toff ? c->toff : nullptr;
     a.lambda = c->lambda;
     a.t = t;
@@ -461,11 +484,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         default: return OCEAN_E_UNSUPPORTED;
     }
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
-    if (pipe) {
-        HIP_TRY(hipEventRecord(c->done[set], st));
-        c->done_valid[set] = true;
-        c->frame_ctr++;
-    }
+    if (pipe) c->frame_ctr++;
     c->last_set = set;
     return OCEAN_OK;
 }
@@ -544,8 +563,8 @@ int ocean_read_maps(ocean_t* c, uint32_t first, uint32_t count, float* disp, flo
     if (!c->prepared) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
-    const float4* d = (c->ext_disp ? c->ext_disp : c->disp) + first * n2;
-    const float4* q = (c->ext_nrm ? c->ext_nrm : c->nrm) + first * n2;
+    const float4* d = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + first * n2;
+    const float4* q = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + first * n2;
     SYNC_ALL(c);
     if (disp) HIP_TRY(hipMemcpy(disp, d, count * n2 * sizeof(float4), hipMemcpyDeviceToHost));
     if (nrm) HIP_TRY(hipMemcpy(nrm, q, count * n2 * sizeof(float4), hipMemcpyDeviceToHost));
@@ -555,8 +574,8 @@ int ocean_read_maps(ocean_t* c, uint32_t first, uint32_t count, float* disp, flo
 int ocean_device_maps(ocean_t* c, void** d_disp, void** d_nrm)
 {
     if (!c) return OCEAN_E_INVALID;
-    if (d_disp) *d_disp = c->ext_disp ? (void*)c->ext_disp : (void*)c->disp;
-    if (d_nrm) *d_nrm = c->ext_nrm ? (void*)c->ext_nrm : (void*)c->nrm;
+    if (d_disp) *d_disp = c->ext_disp ? (void*)c->ext_disp : (void*)c->dispN[c->last_set];
+    if (d_nrm) *d_nrm = c->ext_nrm ? (void*)c->ext_nrm : (void*)c->nrmN[c->last_set];
     return OCEAN_OK;
 }
 
@@ -580,7 +599,6 @@ int ocean_set_stream(ocean_t* c, void* s)
     SYNC_ALL(c);
     c->user = (hipStream_t)s;
     c->last_set = 0;
-    c->done_valid[0] = c->done_valid[1] = false;
     return OCEAN_OK;
 }
 
@@ -630,11 +648,10 @@ int ocean_set_spectrum_precision(ocean_t* c, int bits)
 
 int ocean_set_pipeline_depth(ocean_t* c, int depth)
 {
-    if (!c || (depth != 1 && depth != 2)) return OCEAN_E_INVALID;
+    if (!c || depth < 1 || depth > MAXD) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
     c->depth = depth;
-    c->done_valid[0] = c->done_valid[1] = false;
     return OCEAN_OK;
 }
 
@@ -647,15 +664,20 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     for (int j = 0; j < warmup; ++j)
         if ((rc = enqueue_frame(c, t0 + dt * (float)j, true, nullptr))) return rc;
     SYNC_ALL(c);
-    HIP_TRY(hipEventRecord(c->ev[4], stream_of(c, (int)(c->frame_ctr & 1))));
+    HIP_TRY(hipEventRecord(c->ev[4], stream_of(c, 0)));
+    HIP_TRY(hipEventSynchronize(c->ev[4]));
     for (int j = 0; j < frames; ++j)
         if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), true, nullptr))) return rc;
-    // frame f's column passes wait for frame f-1's, so the last frame ends last
-    HIP_TRY(hipEventRecord(c->ev[5], stream_of(c, c->last_set)));
-    HIP_TRY(hipEventSynchronize(c->ev[5]));
+    // the two chains are independent: the timed region ends when the later one does
+    const int nstreams = c->user ? 1 : MAXD;
+    for (int i = 0; i < nstreams; ++i) HIP_TRY(hipEventRecord(c->end_ev[i], stream_of(c, i)));
     SYNC_ALL(c);
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+    for (int i = 0; i < nstreams; ++i) {
+        float m = 0.f;
+        HIP_TRY(hipEventElapsedTime(&m, c->ev[4], c->end_ev[i]));
+        if (m > ms) ms = m;
+    }
     if (ms_total) *ms_total = ms;
     if (ms_kernel) {
         // second pass, one frame at a time on one stream: events around every

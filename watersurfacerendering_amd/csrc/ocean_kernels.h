@@ -818,6 +818,7 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
 
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
+#define OCEAN_R(...) Radices<__VA_ARGS__>
 #define OCEAN_GEO(n, tr, pr, merged, ch, th, cc, tc, pc)                                        \
     template <> struct Geo<n> {                                                                \
         static constexpr int T_ROWS = tr;               /* threads of k_zpass               */ \
@@ -833,7 +834,21 @@ OCEAN_GEO(128, 64, Plan<128>, false, 4, 64, 4, 64, Plan<128>)
 OCEAN_GEO(256, 64, Plan<256>, false, 4, 64, 4, 64, Plan<256>)
 OCEAN_GEO(512, 128, Plan<512>, false, 2, 128, 4, 256, Plan<512>)
 OCEAN_GEO(1024, 128, Plan<1024>, false, 2, 128, 4, 256, Plan<1024>)
+#if defined(OCEAN_V_M)
+OCEAN_GEO(2048, 256, Plan<2048>, true, 2, 256, 4, 512, Plan<2048>)
+#elif defined(OCEAN_V_M2)
+OCEAN_GEO(2048, 256, Plan<2048>, true, 2, 256, 2, 256, Plan<2048>)
+#elif defined(OCEAN_V_A)
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, Plan<2048>)
+#elif defined(OCEAN_V_B)
+OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
+#elif defined(OCEAN_V_C)
+OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, OCEAN_R(8, 8, 8, 4))
+#elif defined(OCEAN_V_D)
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
+#else
 OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, Plan<2048>)
+#endif
 OCEAN_GEO(4096, 512, Plan<4096>, true, 2, 512, 2, 512, Plan<4096>)
 #undef OCEAN_GEO
 
