@@ -16,8 +16,8 @@ synchronise.  With --depth 2 (default) consecutive frames alternate between two
 independent chains (own stream, own intermediates, own map set), so one frame's first
 pass overlaps the other's map passes; every frame is still computed in full and its
 maps stay addressable until the chain is reused.  --depth 1 = strictly serial frames
-(also reported under extra).  Per-launch durations for the roofline object are always
-measured serially (HIP events around each launch, one frame at a time).
+(also reported under extra).  Per-launch durations for the roofline object come from HIP
+events around every launch in the same regime (a second pass of the same frames).
 
 Multi-GPU: tiles are independent, so every rank synthesises its own tile(s)
 with no data-path collective ("weak" scaling, value = frames of all ranks per
@@ -157,9 +157,19 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * tiles * args.steps / elapsed
 
-    # ---- dominant-kernel roofline, measured live with HIP events on the launch stream
-    # (time_frames' per-kernel pass runs one frame at a time on one stream: serial launch durations)
+    # ---- dominant-kernel roofline, measured live with HIP events on the launch stream.
+    # Per-launch durations only characterise a kernel when it has the GPU to itself, so the
+    # roofline object is measured with serial frames (depth 1; `bench.py --depth 1` under
+    # rocprofv3 reproduces them: profiles/).  At depth > 1 launches of consecutive frames
+    # overlap; those durations are reported beside it, and the frame-level fractions cover
+    # the pipelined regime.
+    kern_ms_pipe = None
+    if args.depth > 1:
+        _, kern_ms_pipe = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
+        b.set_pipeline_depth(1)
     ms_serial, kern_ms = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
+    serial_us_per_step = ms_serial / min(args.steps, 100) * 1e3
+    b.set_pipeline_depth(args.depth)
     KERNEL_ORDER = b.kernel_names()
     dom = max(range(3), key=lambda i: kern_ms[i])
     dom_name = KERNEL_ORDER[dom]
@@ -180,7 +190,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_us": kern_ms[dom] * 1e3,
-                "launch_us_mode": "one frame at a time on one stream (HIP events around each launch)",
+                "regime": "serial frames (pipeline depth 1): HIP events around every launch, one frame at a time; "
+                          "event intervals include ~2.5-3 us of launch/event processing per launch vs rocprofv3",
+                "serial_us_per_step": serial_us_per_step,
+                "serial_frame_frac": FRAME_BYTES_SURVEY * n * n * tiles / (serial_us_per_step * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+                "pipelined_kernel_us": ({k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern_ms_pipe)} if kern_ms_pipe else None),
+                "pipelined_depth": args.depth,
                 "bytes_model": "SURVEY.md 8d (108 B/texel per frame) apportioned per launch",
                 "achieved_on_this_pipelines_own_bytes": dom_bytes_actual / (kern_ms[dom] * 1e-3) * 1e-9,
                 "own_bytes_per_launch": dom_bytes_actual,

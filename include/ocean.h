@@ -158,11 +158,12 @@ int ocean_read_spectrum(ocean_t* ctx, uint32_t tile, float* h0, float* omega);
 /* Copies the generated gaussian draws of one tile (N*N*2).                      */
 int ocean_read_xi(ocean_t* ctx, uint32_t tile, float* xi);
 
-/* Times `frames` back-to-back frames (t = t0 + j*dt) with HIP events on the
- * context's stream after `warmup` untimed ones.  ms_total = whole timed region;
- * ms_kernel[3] = mean duration per launch of {row pass, column pass B (height +
- * normal map), column pass C (displacement map)}, measured with events bracketing each launch on a second,
- * separately timed run of the same frames.  Any output pointer may be NULL.     */
+/* Times `frames` back-to-back asynchronous frames (t = t0 + j*dt) with HIP events after
+ * `warmup` untimed ones, at the context's pipeline depth.  ms_total = whole timed region;
+ * ms_kernel[3] = mean duration per launch, in ocean_kernel_name order, from events
+ * bracketing every launch on its own stream during a second, separately timed run of
+ * the same frames in the same regime (at depth > 1 the launches of different frames
+ * overlap, so these are durations under that concurrency).  Any output pointer may be NULL. */
 int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
                       float* ms_total, float* ms_kernel /* [3] */);
 

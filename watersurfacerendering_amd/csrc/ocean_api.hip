@@ -27,7 +27,7 @@ static thread_local int g_last_hip = 0;
         }                                               \
     } while (0)
 
-static constexpr int MAXD = 4;     // maximum pipeline depth (independent frame chains)
+static constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
 
 struct ocean_ctx {
     uint32_t n = 0;
@@ -72,6 +72,7 @@ struct ocean_ctx {
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t ev[8] = {};
     hipEvent_t end_ev[MAXD] = {};
+    hipEvent_t mark_ev[MAXD][4] = {};   // per-launch timing in pipelined mode
 };
 
 static void free_device(ocean_ctx* c)
@@ -206,6 +207,7 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
         if (hipHostMalloc((void**)&c->h_minmax, tiles * 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& e : c->end_ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
+        for (auto& row : c->mark_ev) for (auto& e : row) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         if (rc) break;
         rc = alloc_device(c);
     } while (0);
@@ -223,6 +225,7 @@ void ocean_destroy(ocean_t* c)
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& row : c->mark_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) (void)hipStreamDestroy(c->own[i]);
     delete c;
@@ -680,19 +683,44 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     }
     if (ms_total) *ms_total = ms;
     if (ms_kernel) {
-        // second pass, one frame at a time on one stream: events around every
-        // launch (adds event overhead; reported separately, never mixed into ms_total)
+        // second pass over the same frames with events around every launch, in the SAME
+        // regime as the timed region: at depth D the chains keep running ahead (the host
+        // only waits for a chain's previous frame before reusing its events), so the
+        // durations include whatever the concurrent frames cost each other.  Event
+        // overhead is why this is a separate pass, never mixed into ms_total.
+        const bool pipe = c->depth > 1 && !c->user && !c->ext_disp && !c->ext_nrm;
+        const int nsets = pipe ? c->depth : 1;
         double acc[3] = {0, 0, 0};
-        for (int j = 0; j < frames; ++j) {
-            if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), false, c->ev))) return rc;
-            HIP_TRY(hipEventSynchronize(c->ev[3]));
+        long counted = 0;
+        auto collect = [&](int set) -> int {
+            HIP_TRY(hipEventSynchronize(c->mark_ev[set][3]));
             for (int k = 0; k < 3; ++k) {
                 float m = 0.f;
-                HIP_TRY(hipEventElapsedTime(&m, c->ev[k], c->ev[k + 1]));
+                HIP_TRY(hipEventElapsedTime(&m, c->mark_ev[set][k], c->mark_ev[set][k + 1]));
                 acc[k] += m;
             }
+            ++counted;
+            return OCEAN_OK;
+        };
+        if (!pipe) {
+            // serial frames: one frame at a time (least event-queueing overhead, ~2 us per launch)
+            for (int j = 0; j < frames; ++j) {
+                if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), true, c->mark_ev[0]))) return rc;
+                if ((rc = collect(0))) return rc;
+            }
+        } else {
+            for (int j = 0; j < frames; ++j) {
+                const int set = (int)(c->frame_ctr % (uint64_t)c->depth);
+                if (j >= nsets && (rc = collect(set))) return rc;
+                if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), true, c->mark_ev[set]))) return rc;
+            }
+            for (int k = 0; k < (frames < nsets ? frames : nsets); ++k) {
+                const int set = (int)((c->frame_ctr + (uint64_t)k) % (uint64_t)c->depth);
+                if ((rc = collect(set))) return rc;
+            }
         }
-        for (int k = 0; k < 3; ++k) ms_kernel[k] = (float)(acc[k] / frames);
+        SYNC_ALL(c);
+        for (int k = 0; k < 3; ++k) ms_kernel[k] = (float)(acc[k] / (double)(counted > 0 ? counted : 1));
     }
     return OCEAN_OK;
 }
