@@ -1,0 +1,13 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import watersurfacerendering_amd as W
+n = int(sys.argv[1]); tiles = int(sys.argv[2]); depths = [int(x) for x in sys.argv[3].split(",")]
+out = []
+for depth in depths:
+    b = W.OceanBatch(n, tiles, 0); b.prepare(1); b.set_pipeline_depth(depth)
+    frames = 100
+    ms, _ = b.time_frames(0.0, 0.05, 10, frames, per_kernel=False)
+    per = ms / frames * 1e3
+    out.append(f"d{depth}={per:.1f}us ({n*n*tiles/per/1e3:.1f} Gtexel/s)")
+    b.close()
+print(f"N={n} tiles={tiles} " + " ".join(out))

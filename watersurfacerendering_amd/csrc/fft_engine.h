@@ -181,6 +181,28 @@ template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() *
 template <int C>
 __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
 
+// Work-item -> (column c, butterfly j) of the LAST stage.  Default: c fastest (as in the
+// other stages).  For a batch whose items fill whole waves (and unless built with
+// -DOCEAN_LAST_CFASTEST), the
+// 64 lanes of a wave cover 64/C consecutive j of ONE column each, so a wave's store
+// instruction writes 64/C consecutive outputs per column contiguously (whole 128-byte
+// lines per 16-lane group) instead of C-interleaved 64-byte pieces.
+template <int N, int C, int R>
+__device__ __forceinline__ void last_stage_map(int w, int& c, int& j)
+{
+#ifndef OCEAN_LAST_CFASTEST
+    constexpr int ITEMS = (N / R) * C;
+    if constexpr (ITEMS % 64 == 0 && 64 % C == 0 && C > 1) {
+        constexpr int JB = 64 / C;
+        c = (w / JB) % C;
+        j = (w % JB) + JB * (w / 64);
+        return;
+    }
+#endif
+    c = w % C;
+    j = w / C;
+}
+
 // Base twiddles of every (stage, work item) of one thread, fetched ONCE per kernel
 // into registers (a handful of VGPRs): the table loads then overlap the kernel's
 // first global loads instead of sitting on the critical path of every transform.
@@ -203,7 +225,11 @@ template <int N, int C, int T, class P> struct TwiddleRegs {
 #pragma unroll
         for (int u = 0; u < IT; ++u) {
             const int wi = tid + u * T;
-            const int j = (wi < ITEMS ? wi : 0) / C;
+            int j = (wi < ITEMS ? wi : 0) / C;
+            if constexpr (STAGE == P::S - 1) {
+                int c_unused;
+                last_stage_map<N, C, R>(wi < ITEMS ? wi : 0, c_unused, j);
+            }
             if constexpr (NS > 1) w[STAGE][u] = tw[(j % NS) * (N / (NS * R))];
             else w[STAGE][u] = make_float2(1.f, 0.f);
         }
@@ -230,7 +256,8 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
         for (int u = 0; u < IT; ++u) {
             const int w = tid + u * T;
             if (!GUARD || w < ITEMS) {
-                const int c = w % C, j = w / C;
+                int c, j;
+                last_stage_map<N, C, R>(w, c, j);
                 c32 x[R];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -337,6 +364,7 @@ template <int N, int C, int T, class P = Plan<N>> struct LastStage {
     static constexpr int IT = (ITEMS + T - 1) / T;
     static constexpr bool GUARD = (ITEMS % T) != 0;
     static constexpr int STRIDE = N / RL;
+    static __device__ __forceinline__ void map(int w, int& c, int& j) { last_stage_map<N, C, RL>(w, c, j); }
 };
 
 }  // namespace ocean

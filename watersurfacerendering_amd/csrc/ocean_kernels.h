@@ -616,7 +616,8 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
     for (int u = 0; u < LS::IT; ++u) {
         const int w = tid + u * T;
         if (!LS::GUARD || w < LS::ITEMS) {
-            const int c = w % C, j = w / C;
+            int c, j;
+            LS::map(w, c, j);
 #pragma unroll
             for (int i = 0; i < LS::RL; ++i) hv[u][i] = hraw[hraw_index(N, j + i * LS::STRIDE, u0 + c)];
         }
@@ -794,7 +795,8 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
     for (int u = 0; u < LS::IT; ++u) {
         const int w = tid + u * T;
         if (!LS::GUARD || w < LS::ITEMS) {
-            const int c = w % C, j = w / C;
+            int c, j;
+            LS::map(w, c, j);
 #pragma unroll
             for (int i = 0; i < LS::RL; ++i) hv[u][i] = hraw[hraw_index(N, j + i * LS::STRIDE, u0 + c)];
         }
