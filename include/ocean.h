@@ -120,6 +120,17 @@ int ocean_get_heights(ocean_t* ctx, uint32_t tile, float* amp, float* min_h, flo
  *      be NULL.  Synchronous.                                                    */
 int ocean_read_maps(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);
 
+/* Asynchronous read-out (the upload path after ComputeWaves,
+ * WaterSurfaceMesh.cpp:701-755 + vulkan/Buffer.cpp:133-155).  ocean_host_register pins a
+ * caller-owned host range (e.g. the persistently mapped Vulkan staging buffer) so that
+ * ocean_read_maps_async can DMA the maps of the most recently enqueued frame straight into
+ * it, ordered after that frame on its stream, without blocking the caller; the copy is
+ * complete after ocean_synchronize.  With an unregistered (pageable) destination the call
+ * still works but degrades to a synchronous copy.                                       */
+int ocean_host_register(void* host_ptr, size_t bytes);
+int ocean_host_unregister(void* host_ptr);
+int ocean_read_maps_async(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);
+
 /* Device pointers of the maps of tile 0 (tile i at +i*N*N*4 floats): zero-copy
  * hand-off to a device-side consumer (interop, RCCL gather).                     */
 int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);

@@ -376,3 +376,23 @@ def test_pipelined_frames_keep_frame_order_semantics():
     assert np.array_equal(got[0], d1[0]) and np.array_equal(got[1], q1[0])
     pip.bind_output(None, None)
     ref.close(); pip.close()
+
+
+def test_async_readout_into_registered_host_memory():
+    """maps DMA'd straight into a pinned caller buffer laid out like the reference's
+    staging buffer [displacements | normals] (WaterSurfaceMesh.cpp:705-744), ordered after the frame."""
+    import watersurfacerendering_amd as W
+    n = 512
+    b = W.OceanBatch(n, 1, 0); b.prepare(17)
+    staging = np.zeros((2, n, n, 4), dtype=np.float32)
+    W.host_register(staging)
+    try:
+        for t in (0.5, 1.0):
+            b.compute_waves_async(t)
+            b.read_maps_async(staging[0:1], staging[1:2])
+            b.synchronize()
+            d, q = b.read_maps()
+            assert np.array_equal(staging[0], d[0]) and np.array_equal(staging[1], q[0])
+    finally:
+        W.host_unregister(staging)
+    b.close()

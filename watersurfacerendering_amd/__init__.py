@@ -26,7 +26,7 @@ import numpy as np
 from . import _abi
 from ._abi import OceanError, Params, build  # noqa: F401
 
-__all__ = ["WSTessendorf", "OceanBatch", "OceanError", "build"]
+__all__ = ["WSTessendorf", "OceanBatch", "OceanError", "build", "host_register", "host_unregister"]
 
 
 def _is_pow2(n: int) -> bool:
@@ -125,6 +125,13 @@ class OceanBatch:
                                            q.ctypes.data_as(C.c_void_p)), "ocean_read_maps")
         return d, q
 
+    def read_maps_async(self, disp: np.ndarray, nrm: np.ndarray, first: int = 0, count: int | None = None):
+        """Enqueue the D2H copy of the last enqueued frame's maps into caller arrays (pin them with
+        host_register for a true asynchronous DMA); valid after synchronize()."""
+        count = self.tiles - first if count is None else count
+        _abi.check(self._L.ocean_read_maps_async(self._h, first, count, disp.ctypes.data_as(C.c_void_p),
+                                                 nrm.ctypes.data_as(C.c_void_p)), "ocean_read_maps_async")
+
     def device_maps(self):
         d, q = C.c_void_p(), C.c_void_p()
         _abi.check(self._L.ocean_device_maps(self._h, C.byref(d), C.byref(q)), "ocean_device_maps")
@@ -174,6 +181,14 @@ class OceanBatch:
     @property
     def algorithmic_bytes_per_texel(self) -> int:
         return int(self._L.ocean_algorithmic_bytes_per_texel(self._h))
+
+
+def host_register(arr: np.ndarray):
+    _abi.check(_abi.lib().ocean_host_register(arr.ctypes.data_as(C.c_void_p), arr.nbytes), "ocean_host_register")
+
+
+def host_unregister(arr: np.ndarray):
+    _abi.check(_abi.lib().ocean_host_unregister(arr.ctypes.data_as(C.c_void_p)), "ocean_host_unregister")
 
 
 class WSTessendorf:

@@ -29,7 +29,8 @@ SYMBOLS = [
     "ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_set_lambda",
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_set_time_offsets", "ocean_synchronize",
-    "ocean_get_heights", "ocean_read_maps", "ocean_device_maps", "ocean_bind_output",
+    "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
+    "ocean_read_maps_async", "ocean_device_maps", "ocean_bind_output",
     "ocean_set_spectrum_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
     "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
 ]
@@ -93,6 +94,9 @@ def lib() -> C.CDLL:
         "ocean_synchronize": (i32, [P]),
         "ocean_get_heights": (i32, [P, u32, FP, FP, FP]),
         "ocean_read_maps": (i32, [P, u32, u32, C.c_void_p, C.c_void_p]),
+        "ocean_host_register": (i32, [C.c_void_p, C.c_size_t]),
+        "ocean_host_unregister": (i32, [C.c_void_p]),
+        "ocean_read_maps_async": (i32, [P, u32, u32, C.c_void_p, C.c_void_p]),
         "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
         "ocean_bind_output": (i32, [P, P, P]),
         "ocean_set_spectrum_precision": (i32, [P, i32]),

@@ -574,6 +574,34 @@ int ocean_read_maps(ocean_t* c, uint32_t first, uint32_t count, float* disp, flo
     return OCEAN_OK;
 }
 
+int ocean_host_register(void* host_ptr, size_t bytes)
+{
+    if (!host_ptr || bytes == 0) return OCEAN_E_INVALID;
+    HIP_TRY(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return OCEAN_OK;
+}
+
+int ocean_host_unregister(void* host_ptr)
+{
+    if (!host_ptr) return OCEAN_E_INVALID;
+    HIP_TRY(hipHostUnregister(host_ptr));
+    return OCEAN_OK;
+}
+
+int ocean_read_maps_async(ocean_t* c, uint32_t first, uint32_t count, float* disp, float* nrm)
+{
+    if (!c || first >= c->tiles || count == 0 || first + count > c->tiles) return OCEAN_E_INVALID;
+    if (!c->prepared) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    const float4* d = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + first * n2;
+    const float4* q = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + first * n2;
+    hipStream_t st = stream_of(c, c->last_set);          // ordered after the frame that wrote these maps
+    if (disp) HIP_TRY(hipMemcpyAsync(disp, d, count * n2 * sizeof(float4), hipMemcpyDeviceToHost, st));
+    if (nrm) HIP_TRY(hipMemcpyAsync(nrm, q, count * n2 * sizeof(float4), hipMemcpyDeviceToHost, st));
+    return OCEAN_OK;
+}
+
 int ocean_device_maps(ocean_t* c, void** d_disp, void** d_nrm)
 {
     if (!c) return OCEAN_E_INVALID;
