@@ -141,6 +141,15 @@ int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
  * internal buffers.                                                              */
 int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
 
+/* Output mode.  OCEAN_MODE_FULL7 (default) is the reference: all seven fields.  The
+ * reduced modes of BASELINE.json / SURVEY.md 8d compute fewer transforms and leave the
+ * rest of the texel at the value the reference's maps are initialised to in spirit:
+ *   OCEAN_MODE_CHOPPY5  h, Dx, Dz, slope-x, slope-z ("5 iFFTs"); normal.zw = 0
+ *   OCEAN_MODE_HEIGHT1  height only; displacement = (0, h/A, 0, 1), normal = 0
+ * Takes effect at the next frame (no ocean_prepare needed).                              */
+enum { OCEAN_MODE_FULL7 = 0, OCEAN_MODE_CHOPPY5 = 1, OCEAN_MODE_HEIGHT1 = 2 };
+int ocean_set_mode(ocean_t* ctx, int mode);
+
 /* Spectrum storage precision: 32 (default) or 16.  With 16 the per-frame passes read a
  * half2 copy of h0(k), scaled per tile by a power of two, instead of the fp32 one
  * (8 instead of 12 bytes per texel of input; omega stays fp32).  Takes effect at the

@@ -140,6 +140,9 @@ class OceanBatch:
     def bind_output(self, d_disp: int | None, d_nrm: int | None):
         _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")
 
+    def set_mode(self, mode: int):
+        _abi.check(self._L.ocean_set_mode(self._h, mode), "ocean_set_mode")
+
     def set_spectrum_precision(self, bits: int):
         _abi.check(self._L.ocean_set_spectrum_precision(self._h, bits), "ocean_set_spectrum_precision")
 

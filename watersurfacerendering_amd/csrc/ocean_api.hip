@@ -64,6 +64,7 @@ struct ocean_ctx {
     float* lambda = nullptr;
     TileParams* tparams = nullptr;
     float2* xi = nullptr;          // injected or generated draws (kept for read-back)
+    int mode = 0;                  // OCEAN_MODE_*
     int h0_bits = 32;              // 32, or 16: frames read a scaled half2 copy of h0
     __half2* h0h = nullptr;
     float* h0_inv_scale = nullptr;
@@ -473,6 +474,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.toff = c->use_toff ? c->toff : nullptr;
     a.lambda = c->lambda;
     a.t = t;
+    a.mode = c->mode;
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
         case 16: e = launch_frame<16>(c, a, st, wait, marks); break;
@@ -666,6 +668,13 @@ int ocean_read_xi(ocean_t* c, uint32_t tile, float* xi)
     const size_t n2 = (size_t)c->n * c->n;
     SYNC_ALL(c);
     HIP_TRY(hipMemcpy(xi, c->xi + tile * n2, n2 * sizeof(float2), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int ocean_set_mode(ocean_t* c, int mode)
+{
+    if (!c || mode < OCEAN_MODE_FULL7 || mode > OCEAN_MODE_HEIGHT1) return OCEAN_E_INVALID;
+    c->mode = mode;                 // takes effect at the next frame, like SetLambda
     return OCEAN_OK;
 }
 

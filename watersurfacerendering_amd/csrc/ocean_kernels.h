@@ -84,6 +84,7 @@ struct FrameArgs {
     const float* toff;       // [tiles] or null
     const float* lambda;     // [tiles]
     float t;
+    int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only)
 };
 
 
@@ -321,7 +322,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         }
     };
     // -- batch A: slot 0 = pair 0 (Dx, Dz), slot 1 = pair 1 (sx, sz) ------------
-    {
+    if (a.mode != 2) {
         auto in = [&](int e, int c, int, int) -> c32 {
             float sv, tx, tz;
             fetch(e, sv, tx, tz);
@@ -346,6 +347,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         OCEAN_STAMP(2);
     }
     // -- batch B: slot 0 = pair 2 (dDx/dx, dDz/dz), slot 1 = height ----------------
+    const float full7 = (a.mode == 0) ? 1.0f : 0.0f;
     {
         auto in = [&](int e, int c, int, int) -> c32 {
             float sv, tx, tz;
@@ -357,7 +359,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             const float kz2 = kz * kz;
             const float d = kx2 + kz2;
             const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;
-            const float g = inv * sv;
+            const float g = full7 * inv * sv;                      // pair 2 only exists in the 7-field mode
             return make_float2(c ? sv : kx2 * g, c ? 0.0f : kz2 * g);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
@@ -512,6 +514,23 @@ __device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, i
     return make_float2(eps * v.x, eps * v.y);
 }
 
+// Visits the outputs (position p, column c) the LAST stage of a transform would hand to this
+// thread -- used by the reduced modes that skip a transform but still have to write its texels.
+template <class LS, int T, class F>
+__device__ __forceinline__ void for_each_output(int tid, F f)
+{
+#pragma unroll
+    for (int u = 0; u < LS::IT; ++u) {
+        const int w = tid + u * T;
+        if (!LS::GUARD || w < LS::ITEMS) {
+            int c, j;
+            LS::map(w, c, j);
+#pragma unroll
+            for (int i = 0; i < LS::RL; ++i) f(j + i * LS::STRIDE, c, u, i);
+        }
+    }
+}
+
 // ============================================================================
 // k_xpass_height: 2*C rows of the height per workgroup (C transforms of two real
 // rows each: Y_u + i Y_{u+1}), sign, raw signed height out, global min/max.
@@ -628,26 +647,44 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
     const float lambda = a.lambda[tile];
 
+    auto emit_disp = [&](int p, int c, c32 v, int u, int i) {
+        const int q = u0 + c;
+        if (q > N / 2) return;                                       // padding row
+        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+        // (sign*lambda)*Re Dx, h/A, (sign*lambda)*Re Dz, 1   (.cpp:394-403)
+        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
+#ifdef OCEAN_ABL_NOSTORE
+        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z)); if (p >= 0) return;
+#endif
+        OCEAN_STORE(&disp[(unsigned)(q * N + p)], o);                // texel (row q, column p)
+        if (q != 0 && q != N / 2)                                    // mirror: Dx, Dz odd, height even
+            OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
+    };
+    auto emit_nrm = [&](int p, int c, c32 slopes, c32 derivs) {
+        const int q = u0 + c;
+        if (q > N / 2) return;
+        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+        // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
+        const float4 o = make_float4(s * slopes.x, s * slopes.y, s * derivs.x, s * derivs.y);
+#ifdef OCEAN_ABL_NOSTORE
+        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); if (p >= 0) return;
+#endif
+        OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
+        if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
+            OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
+    };
+    const c32 zero = make_float2(0.0f, 0.0f);
+    if (a.mode == 2) {               // HEIGHT1: height only, no transforms in this pass
+        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { emit_disp(p, c, zero, u, i); emit_nrm(p, c, zero, zero); });
+        return;
+    }
     // ---- pair 0 -> displacement map -----------------------------------------------
     {
         auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
-        auto out = [&](int p, int c, c32 v, int u, int i) {
-            const int q = u0 + c;
-            if (q > N / 2) return;                                       // padding row
-            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-            // (sign*lambda)*Re Dx, h/A, (sign*lambda)*Re Dz, 1   (.cpp:394-403)
-            const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
-#ifdef OCEAN_ABL_NOSTORE
-            asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z)); if (p >= 0) return;
-#endif
-            OCEAN_STORE(&disp[(unsigned)(q * N + p)], o);                             // texel (row q, column p)
-            if (q != 0 && q != N / 2)                                    // mirror: Dx, Dz odd, height even
-                OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
-        };
-        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, emit_disp);
     }
     OCEAN_STAMP(1);
-    fetch(z2, 1.0f, xa);             // pair 2 inputs travel while pair 1 is transformed
+    if (a.mode == 0) fetch(z2, 1.0f, xa);        // pair 2 inputs travel while pair 1 is transformed
     // ---- pairs 1 and 2 -> normal map -----------------------------------------------
     c32 held[LS::IT][LS::RL];
     {
@@ -656,21 +693,13 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
     OCEAN_STAMP(2);
+    if (a.mode == 1) {               // CHOPPY5: slopes only
+        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { emit_nrm(p, c, held[u][i], zero); });
+        return;
+    }
     {
         auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
-        auto out = [&](int p, int c, c32 v, int u, int i) {
-            const int q = u0 + c;
-            if (q > N / 2) return;
-            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-            // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
-            const float4 o = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
-#ifdef OCEAN_ABL_NOSTORE
-            asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); if (p >= 0) return;
-#endif
-            OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
-            if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-                OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
-        };
+        auto out = [&](int p, int c, c32 v, int u, int i) { emit_nrm(p, c, held[u][i], v); };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
     OCEAN_STAMP(3);
@@ -747,26 +776,36 @@ __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
     const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
     float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
     c32 held[LS::IT][LS::RL];
+    auto emit = [&](int p, int c, c32 slopes, c32 derivs) {
+        const int q = u0 + c;
+        if (q > N / 2) return;                                      // padding row
+        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+        // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
+        const float4 o = make_float4(s * slopes.x, s * slopes.y, s * derivs.x, s * derivs.y);
+        OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
+        if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
+            OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
+    };
+    const c32 zero = make_float2(0.0f, 0.0f);
+    if (a.mode == 2) {               // HEIGHT1: the normal map is all zero
+        for_each_output<LS, T>(tid, [&](int p, int c, int, int) { emit(p, c, zero, zero); });
+        return;
+    }
     {
         auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z1, nf, u0 + c, -1.0f); };
         auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    }
+    if (a.mode == 1) {               // CHOPPY5: slopes only
+        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { emit(p, c, held[u][i], zero); });
+        return;
     }
     // keep the second transform's loads from being hoisted over the first one's last
     // stage: that costs ~45 VGPRs and with them the second workgroup per CU
     __builtin_amdgcn_sched_barrier(0);
     {
         auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z2, nf, u0 + c, 1.0f); };
-        auto out = [&](int p, int c, c32 v, int u, int i) {
-            const int q = u0 + c;
-            if (q > N / 2) return;                                      // padding row
-            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-            // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
-            const float4 o = make_float4(s * held[u][i].x, s * held[u][i].y, s * v.x, s * v.y);
-            OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
-            if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-                OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
-        };
+        auto out = [&](int p, int c, c32 v, int u, int i) { emit(p, c, held[u][i], v); };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
 }
@@ -815,6 +854,10 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
         if (q != 0 && q != N / 2)
             OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
     };
+    if (a.mode == 2) {               // HEIGHT1: no horizontal displacement, no transform
+        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
+        return;
+    }
     batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 }
 
