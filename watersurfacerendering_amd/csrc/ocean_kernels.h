@@ -878,8 +878,14 @@ OCEAN_GEO(64, 64, Plan<64>, false, 4, 64, 4, 64, Plan<64>)
 OCEAN_GEO(128, 64, Plan<128>, false, 4, 64, 4, 64, Plan<128>)
 OCEAN_GEO(256, 64, Plan<256>, false, 4, 64, 4, 64, Plan<256>)
 OCEAN_GEO(512, 128, Plan<512>, false, 2, 128, 4, 256, Plan<512>)
+#if defined(OCEAN_V_R16)
 OCEAN_GEO(1024, 128, Plan<1024>, false, 2, 128, 4, 256, Plan<1024>)
-#if defined(OCEAN_V_M)
+#else
+OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), false, 2, 128, 4, 256, Plan<1024>)     // radix-8 z pass: -9 %
+#endif
+#if defined(OCEAN_V_S2)
+OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 2, 256, Plan<2048>)
+#elif defined(OCEAN_V_M)
 OCEAN_GEO(2048, 256, Plan<2048>, true, 2, 256, 4, 512, Plan<2048>)
 #elif defined(OCEAN_V_M2)
 OCEAN_GEO(2048, 256, Plan<2048>, true, 2, 256, 2, 256, Plan<2048>)
@@ -891,10 +897,17 @@ OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
 OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, OCEAN_R(8, 8, 8, 4))
 #elif defined(OCEAN_V_D)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
-#else
+#elif defined(OCEAN_V_R16)
 OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, Plan<2048>)
+#else
+// z pass on radix-8 butterflies with 512 threads (100 VGPRs, 4 waves/SIMD): ~1.5 % faster than radix 16 / 256 threads
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, Plan<2048>)
 #endif
+#if defined(OCEAN_V_R16)
 OCEAN_GEO(4096, 512, Plan<4096>, true, 2, 512, 2, 512, Plan<4096>)
+#else
+OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), true, 2, 512, 2, 512, Plan<4096>)    // radix-8 z pass: -4.5 %
+#endif
 #undef OCEAN_GEO
 
 }  // namespace ocean
