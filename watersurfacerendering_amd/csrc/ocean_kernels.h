@@ -897,6 +897,10 @@ OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
 OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, OCEAN_R(8, 8, 8, 4))
 #elif defined(OCEAN_V_D)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
+#elif defined(OCEAN_V_X1)
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, OCEAN_R(8, 16, 16))
+#elif defined(OCEAN_V_X2)
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, OCEAN_R(16, 8, 16))
 #elif defined(OCEAN_V_R16)
 OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, Plan<2048>)
 #else
