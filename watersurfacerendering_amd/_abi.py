@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _BUILT_LIB = os.path.join(_PKG, "libocean_hip.so")
@@ -72,6 +73,15 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the ocean synthesis path.")
+    # PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If this library
+    # (linked against /opt/rocm) is loaded first and torch afterwards, the process ends up with
+    # two HSA runtimes and the second one cannot open the GPU.  Loading torch's copy first makes
+    # the dynamic linker satisfy our libamdhip64.so.7 dependency with it: one runtime either way.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     P, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
     FP = C.POINTER(C.c_float)
