@@ -62,6 +62,12 @@ def test_argument_checking_without_device(abi):
     assert L.ocean_compute_waves(None, 0.0, None) == abi.OCEAN_E_INVALID
     assert L.ocean_prepare(None, 0, None) == abi.OCEAN_E_INVALID
     assert L.ocean_tile_size(None) == 0
+    assert L.ocean_set_mode(None, 0) == abi.OCEAN_E_INVALID
+    assert L.ocean_set_pipeline_depth(None, 2) == abi.OCEAN_E_INVALID
+    assert L.ocean_set_spectrum_precision(None, 16) == abi.OCEAN_E_INVALID
+    assert L.ocean_host_register(None, 16) == abi.OCEAN_E_INVALID
+    assert L.ocean_read_maps_async(None, 0, 1, None, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_kernel_name(None, 0) is None
     L.ocean_destroy(None)
 
 

@@ -247,6 +247,11 @@ def test_errors_and_ordering():
     b.set_tile_size(32)                       # resize invalidates the prepared state
     with pytest.raises(W.OceanError):
         b.compute_waves(0.0)
+    for bad in (lambda: b.set_mode(3), lambda: b.set_pipeline_depth(0), lambda: b.set_pipeline_depth(99),
+                lambda: b.set_spectrum_precision(8)):
+        with pytest.raises(W.OceanError):
+            bad()
+    assert b.kernel_names() == ["k_zpass", "k_xpass_b", "k_xpass_disp"]
     b.close()
 
 

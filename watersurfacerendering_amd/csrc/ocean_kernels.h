@@ -398,7 +398,6 @@ template <int N, int T, class P = Plan<N>, bool H16 = false>
 __global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using HF = Half<N>;
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // 2 interleaved transforms
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());    // S+ [N]
     float* kzt = sp + N;                                                   // kz table [N]
