@@ -127,3 +127,12 @@ def test_cpp_adaptor_has_reference_surface_and_links(abi, tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([str(exe), "64"], capture_output=True, text=True)
         assert r.returncode == 3 and "no usable HIP device" in r.stderr   # loud failure, no fallback
+
+
+def test_missing_extension_fails_loudly():
+    """No silent fallback: without the built .so the package refuses to work."""
+    code = ("import watersurfacerendering_amd as W\n"
+            "try:\n    W.OceanBatch(64)\nexcept ImportError as e:\n    print('LOUD', e)\n")
+    env = dict(os.environ, OCEAN_HIP_LIB="/nonexistent/libocean_hip.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert "LOUD" in r.stdout and "no CPU fallback" in r.stdout.replace("There is no CPU fallback", "no CPU fallback")

@@ -382,7 +382,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * CH) == 0 && HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb = HF::NUP / (2 * CH), hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};             // function attributes are per device
+    bool& attr_done = attr_done_dev[c->device & 63];
     if (!attr_done) {
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true>, lds_rows)) != hipSuccess) return e;
