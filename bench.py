@@ -86,12 +86,33 @@ def cpu_baseline(n: int, budget_s: float):
             break
     times.sort()
     med = times[len(times) // 2]
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # BASELINE config 1: 256 x 256, height only (1 iFFT), CPU path only (plumbing)
+    o1 = O.Oracle(256)
+    o1.prepare(seed=SEED)
+    o1.compute_waves(0.0, mode=O.MODE_HEIGHT1, fft=O.FFT_F32, copy=False)
+    t1 = []
+    for j in range(20):
+        t0 = time.perf_counter()
+        o1.compute_waves(DT * j, mode=O.MODE_HEIGHT1, fft=O.FFT_F32, copy=False)
+        t1.append(time.perf_counter() - t0)
+    t1.sort()
     return {
         "value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port",
         "sample": f"{len(times)} frames of the same {n}x{n} 7-field workload after 2 warm-up frames, median "
                   f"({med * 1e3:.1f} ms/frame); FFTW not available on this host: baseline is the oracle's own "
                   f"float Stockham FFT in the reference's OpenMP shape (7 single-threaded 2-D FFTs in parallel)",
         "gtexels_per_s": n * n / med * 1e-9,
+        "host": {"cpu_model": model, "nproc": os.cpu_count(), "omp_max_threads": threads,
+                 "note": "stage D of the reference shape (7 single-threaded 2-D FFTs in omp sections) cannot use more than 7 threads"},
+        "config1_256x256_height_only_cpu_ms": t1[len(t1) // 2] * 1e3,
     }
 
 
