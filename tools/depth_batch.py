@@ -4,7 +4,10 @@ import watersurfacerendering_amd as W
 n = int(sys.argv[1]); tiles = int(sys.argv[2]); depths = [int(x) for x in sys.argv[3].split(",")]
 out = []
 for depth in depths:
-    b = W.OceanBatch(n, tiles, 0); b.prepare(1); b.set_pipeline_depth(depth)
+    b = W.OceanBatch(n, tiles, 0)
+    if os.environ.get('OCEAN_FP16'): b.set_spectrum_precision(16)
+    if os.environ.get('OCEAN_MODE'): b.set_mode(int(os.environ['OCEAN_MODE']))
+    b.prepare(1); b.set_pipeline_depth(depth)
     frames = 100
     ms, _ = b.time_frames(0.0, 0.05, 10, frames, per_kernel=False)
     per = ms / frames * 1e3

@@ -476,6 +476,10 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.lambda = c->lambda;
     a.t = t;
     a.mode = c->mode;
+    // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
+    a.stream_maps = (c->n >= 4096 || pipe) ? 1 : 0;
+    static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs)
+    if (stream_env) a.stream_maps = atoi(stream_env);
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
         case 16: e = launch_frame<16>(c, a, st, wait, marks); break;

@@ -43,18 +43,18 @@ __device__ __forceinline__ void store_nt(float4* p, float4 v)
     ocean_f4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<ocean_f4*>(p));
 }
-// Map stores: plain where the maps still fit the 256 MiB Infinity Cache beside the
-// intermediates (N <= 2048, measured 2-4 % faster), non-temporal above (4096: +10 %).
-template <int N> __device__ __forceinline__ void store_map(float4* p, float4 v)
+// Map stores.  The maps are written once and never read back by this pipeline, while the
+// intermediates (Z, hraw) and the spectrum are re-read every frame and fit the 256 MiB
+// memory-side cache: when several frames are in flight a non-temporal map store keeps the
+// output stream from evicting that resident set (2048^2, depth 2: -8 % frame time).  A lone
+// serial frame prefers plain stores (the cache then buffers the write burst: +6 % with
+// non-temporal), so the host picks per launch (FrameArgs::stream_maps).
+__device__ __forceinline__ void store_map(float4* p, float4 v, int streaming)
 {
-#ifdef OCEAN_NT_STORES
-    store_nt(p, v);
-#else
-    if constexpr (N >= 4096) store_nt(p, v);
+    if (streaming) store_nt(p, v);
     else *p = v;
-#endif
 }
-#define OCEAN_STORE(ptr, val) store_map<N>((ptr), (val))
+#define OCEAN_STORE(ptr, val) store_map((ptr), (val), a.stream_maps)
 
 struct TileParams {          // device copy of one tile's properties
     float wind_x, wind_y;    // unit vector (SetWindDirection, .cpp:476-479)
@@ -85,6 +85,7 @@ struct FrameArgs {
     const float* lambda;     // [tiles]
     float t;
     int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only)
+    int stream_maps;         // 1 = write the maps with non-temporal stores (see store_map)
 };
 
 
