@@ -143,11 +143,20 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # OCEAN_BENCH_BACKEND=gloo is a developer switch: it lets the multi-rank control flow be exercised on a
+    # box with fewer GPUs than ranks (ranks then share devices; RCCL refuses that).  The driver never sets it.
+    backend = os.environ.get("OCEAN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = str(dev) if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import watersurfacerendering_amd as W
     from watersurfacerendering_amd import dist as wdist
@@ -174,7 +183,7 @@ def main():
         b.compute_waves_async(DT * (args.warmup + j))
     sync(); barrier(); sync()
     elapsed = time.perf_counter() - t0
-    elapsed = wdist.max_over_ranks(elapsed, device=str(dev))
+    elapsed = wdist.max_over_ranks(elapsed, device=red_dev)
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * tiles * args.steps / elapsed
 
@@ -238,11 +247,11 @@ def main():
         for j in range(reps):
             b.compute_waves_async(DT * j)
             b.synchronize()
-            wdist.gather_maps(maps, dst=0)
+            wdist.gather_maps(maps if backend == "nccl" else maps.cpu(), dst=0)
         torch.cuda.synchronize(); barrier()
-        serial = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=str(dev))
+        serial = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
         gather = {"what": "every step followed by one torch.distributed.gather (RCCL) of the packed maps to rank 0",
-                  "bytes_per_rank": int(maps.numel() * 4), "ms_per_step_serial": serial * 1e3,
+                  "backend": backend, "bytes_per_rank": int(maps.numel() * 4), "ms_per_step_serial": serial * 1e3,
                   "frames_per_s_serial": world * tiles / serial}
 
     out = None
