@@ -266,6 +266,7 @@ def main():
             extra["512x512_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20)
             extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 300, 20, depth=4)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
+            extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 100, 10, depth=2)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)
             extra["4096x4096_fp32_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 30, 6, depth=2)
             extra["4096x4096_fp16_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 30, 6, h0_bits=16, depth=2)
