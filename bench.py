@@ -116,18 +116,22 @@ def cpu_baseline(n: int, budget_s: float):
     }
 
 
-def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1):
+def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1, mode=0):
     b = W.OceanBatch(n, tiles, device)
     if h0_bits != 32:
         b.set_spectrum_precision(h0_bits)
+    if mode:
+        b.set_mode(mode)
     b.set_pipeline_depth(depth)
     b.prepare(SEED)
     ms, kern = b.time_frames(0.0, DT, warmup, steps, per_kernel=True)
     per = ms / steps * 1e-3
     KERNEL_ORDER = b.kernel_names()
     b.close()
-    return {"size": n, "tiles_per_step": tiles, "pipeline_depth": depth, "frames_per_s": tiles / per, "us_per_step": per * 1e6,
-            "gtexels_per_s": n * n * tiles / per * 1e-9, "algorithmic_GBps": FRAME_BYTES_SURVEY * n * n * tiles / per * 1e-9,
+    fb = {0: FRAME_BYTES_SURVEY, 1: 92.0, 2: 44.0}[mode] - (4.0 if h0_bits == 16 else 0.0)   # SURVEY.md 8d per mode
+    return {"size": n, "tiles_per_step": tiles, "pipeline_depth": depth, "mode": ["FULL7", "CHOPPY5", "HEIGHT1"][mode],
+            "frames_per_s": tiles / per, "us_per_step": per * 1e6,
+            "gtexels_per_s": n * n * tiles / per * 1e-9, "algorithmic_GBps": fb * n * n * tiles / per * 1e-9,
             "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern)}}
 
 
@@ -250,9 +254,30 @@ def main():
             wdist.gather_maps(maps if backend == "nccl" else maps.cpu(), dst=0)
         torch.cuda.synchronize(); barrier()
         serial = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
-        gather = {"what": "every step followed by one torch.distributed.gather (RCCL) of the packed maps to rank 0",
+        # the same with the gather of frame j-1 overlapped with the synthesis of frame j (two map sets,
+        # the collective on its own stream): SURVEY.md 8e's third figure
+        maps2 = [maps, torch.empty_like(maps)]
+        sync(); barrier()
+        tg = time.perf_counter()
+        work = None
+        for j in range(reps + 1):
+            if j < reps:
+                cur = maps2[j % 2]
+                b.bind_output(cur[0].data_ptr(), cur[1].data_ptr())
+                b.compute_waves_async(DT * j)
+            if j > 0:
+                prev = maps2[(j - 1) % 2]
+                _, work = wdist.gather_maps(prev if backend == "nccl" else prev.cpu(), dst=0, async_op=True)
+            b.synchronize()
+            if work is not None:
+                work.wait()
+        torch.cuda.synchronize(); barrier()
+        overlapped = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
+        gather = {"what": "every step followed by one torch.distributed.gather (RCCL) of the packed maps to rank 0; "
+                          "'overlapped' = the gather of frame j-1 runs beside the synthesis of frame j (two map sets)",
                   "backend": backend, "bytes_per_rank": int(maps.numel() * 4), "ms_per_step_serial": serial * 1e3,
-                  "frames_per_s_serial": world * tiles / serial}
+                  "frames_per_s_serial": world * tiles / serial, "ms_per_step_overlapped": overlapped * 1e3,
+                  "frames_per_s_overlapped": world * tiles / overlapped}
 
     out = None
     if rank == 0:
@@ -265,6 +290,8 @@ def main():
             # BASELINE.json configs beside the headline one (parity for all of them: tests/test_parity_gpu.py)
             extra["512x512_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20)
             extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 300, 20, depth=4)
+            extra["512x512_choppy5_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20, mode=1)
+            extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 300, 20, mode=2)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
             extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 100, 10, depth=2)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)
