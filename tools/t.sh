@@ -1,6 +1,5 @@
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-for N in 512 1024; do
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_s$N -- python3 $R/tools/run_frames.py $N 200 1 > /dev/null 2>&1
-find $R/gpurun_out/prof_s$N -name "*kernel_stats.csv" -exec head -4 {} \;
-done
+python -m pytest tests/test_parity_gpu.py -x -q -m gpu 2>&1 | tail -3
+python tools/quick_bench.py 512,1024,2048,4096
+python tools/depth_batch.py 2048 1 1,2,3
+python tools/depth_batch.py 512 16 1,2
+python tools/depth_batch.py 512 1 1,4

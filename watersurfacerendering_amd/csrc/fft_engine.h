@@ -43,54 +43,96 @@ __device__ __forceinline__ c32 cmul(c32 a, c32 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ c32 cmuli(c32 a) { return make_float2(-a.y, a.x); }   // * (+i)
+
+// ---- packed-fp32 complex arithmetic ------------------------------------------------
+// The butterflies run on 64-bit register pairs (re, im) with CDNA's packed fp32 VALU
+// (v_pk_add/mul/fma_f32: two floats per lane per instruction).  The operand swizzles
+// (op_sel) and per-half negation (neg_lo / neg_hi) of those instructions make a complex
+// multiply two instructions and "b +/- i*a" one; written out here because the compiler
+// reaches the same arithmetic only with 25-30 % extra v_mov / v_xor around it, and these
+// kernels are VALU-issue bound (a wave64 VALU instruction occupies its SIMD for 4 cycles).
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2 tov(c32 a) { return (v2){a.x, a.y}; }
+__device__ __forceinline__ c32 toc(v2 a) { return make_float2(a.x, a.y); }
+
+__device__ __forceinline__ v2 pk_cmul(v2 a, v2 w)           // a * w
+{
+    v2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));          // (a.x w.x, a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                 // (t.x - a.y w.y, t.y + a.y w.x)
+        : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2 pk_add_i(v2 b, v2 a)          // b + i a = (b.x - a.y, b.y + a.x)
+{
+    v2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(b), "v"(a));
+    return d;
+}
+__device__ __forceinline__ v2 pk_sub_i(v2 b, v2 a)          // b - i a = (b.x + a.y, b.y - a.x)
+{
+    v2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(b), "v"(a));
+    return d;
+}
+__device__ __forceinline__ v2 pk_neg_add_i(v2 a)            // -a + i a = (-a.x - a.y, a.x - a.y)
+{
+    v2 d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ v2 pk_muli(v2 a)                 // i a = (-a.y, a.x)
+{
+    v2 d;
+    asm("v_pk_add_f32 %0, 0, %1 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(d) : "v"(a));
+    return d;
+}
 
 // ---- in-register radix-R backward DFTs, natural order in and out ----------
-__device__ __forceinline__ void dft4(c32& x0, c32& x1, c32& x2, c32& x3)
+__device__ __forceinline__ void dft4(v2& x0, v2& x1, v2& x2, v2& x3)
 {
-    const c32 t0 = cadd(x0, x2), t1 = csub(x0, x2);
-    const c32 t2 = cadd(x1, x3), t3 = cmuli(csub(x1, x3));
-    x0 = cadd(t0, t2); x2 = csub(t0, t2);
-    x1 = cadd(t1, t3); x3 = csub(t1, t3);
+    const v2 t0 = x0 + x2, t1 = x0 - x2;
+    const v2 t2 = x1 + x3, d = x1 - x3;
+    x0 = t0 + t2; x2 = t0 - t2;
+    x1 = pk_add_i(t1, d); x3 = pk_sub_i(t1, d);
 }
 
 template <int R> struct Dft;
 
 template <> struct Dft<2> {
-    static __device__ __forceinline__ void run(c32 (&x)[2])
+    static __device__ __forceinline__ void run(v2 (&x)[2])
     {
-        const c32 a = x[0], b = x[1];
-        x[0] = cadd(a, b); x[1] = csub(a, b);
+        const v2 a = x[0], b = x[1];
+        x[0] = a + b; x[1] = a - b;
     }
 };
 
 template <> struct Dft<4> {
-    static __device__ __forceinline__ void run(c32 (&x)[4]) { dft4(x[0], x[1], x[2], x[3]); }
+    static __device__ __forceinline__ void run(v2 (&x)[4]) { dft4(x[0], x[1], x[2], x[3]); }
 };
 
 template <> struct Dft<8> {
-    static __device__ __forceinline__ void run(c32 (&x)[8])
+    static __device__ __forceinline__ void run(v2 (&x)[8])
     {
         // decimation in time: E = DFT4(even), O = DFT4(odd), y[k] = E[k] + w8^k O[k]
         dft4(x[0], x[2], x[4], x[6]);
         dft4(x[1], x[3], x[5], x[7]);
         constexpr float h = 0.70710678118654752440f;
-        const c32 o0 = x[1];
-        const c32 o1 = make_float2(h * (x[3].x - x[3].y), h * (x[3].x + x[3].y));     // * (1+i)/sqrt2
-        const c32 o2 = cmuli(x[5]);                                                    // * i
-        const c32 o3 = make_float2(-h * (x[7].x + x[7].y), h * (x[7].x - x[7].y));    // * (-1+i)/sqrt2
-        const c32 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
-        x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
-        x[1] = cadd(e1, o1); x[5] = csub(e1, o1);
-        x[2] = cadd(e2, o2); x[6] = csub(e2, o2);
-        x[3] = cadd(e3, o3); x[7] = csub(e3, o3);
+        const v2 hh = {h, h};
+        const v2 o0 = x[1];
+        const v2 a1 = pk_add_i(x[3], x[3]);          // (1+i) O1   (times h below)
+        const v2 o2 = x[5];                          // times i, folded into the adds
+        const v2 a3 = pk_neg_add_i(x[7]);            // (-1+i) O3  (times h below)
+        const v2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        x[0] = e0 + o0; x[4] = e0 - o0;
+        x[1] = __builtin_elementwise_fma(a1, hh, e1); x[5] = __builtin_elementwise_fma(a1, -hh, e1);
+        x[2] = pk_add_i(e2, o2); x[6] = pk_sub_i(e2, o2);
+        x[3] = __builtin_elementwise_fma(a3, hh, e3); x[7] = __builtin_elementwise_fma(a3, -hh, e3);
     }
 };
 
 template <> struct Dft<16> {
-    static __device__ __forceinline__ void run(c32 (&x)[16])
+    static __device__ __forceinline__ void run(v2 (&x)[16])
     {
         // n = 4a + b, k = k1 + 4 k2:
         //   Y[k1 + 4 k2] = sum_b w4^(b k2) * [ w16^(b k1) * sum_a x[4a + b] w4^(a k1) ]
@@ -99,16 +141,17 @@ template <> struct Dft<16> {
         // now x[b + 4*k1] = u_b[k1]; multiply by w16^(b*k1)
         constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // w16^1
         constexpr float h = 0.70710678118654752440f;                                   // w16^2 = (h, h)
-        auto mul = [](c32 v, float cr, float ci) { return make_float2(v.x * cr - v.y * ci, v.x * ci + v.y * cr); };
-        x[1 + 4] = mul(x[1 + 4], c1, s1);        // b=1,k1=1 : w^1
-        x[1 + 8] = mul(x[1 + 8], h, h);          // b=1,k1=2 : w^2
-        x[1 + 12] = mul(x[1 + 12], s1, c1);      // b=1,k1=3 : w^3
-        x[2 + 4] = mul(x[2 + 4], h, h);          // b=2,k1=1 : w^2
-        x[2 + 8] = cmuli(x[2 + 8]);              // b=2,k1=2 : w^4 = i
-        x[2 + 12] = mul(x[2 + 12], -h, h);       // b=2,k1=3 : w^6
-        x[3 + 4] = mul(x[3 + 4], s1, c1);        // b=3,k1=1 : w^3
-        x[3 + 8] = mul(x[3 + 8], -h, h);         // b=3,k1=2 : w^6
-        x[3 + 12] = mul(x[3 + 12], -c1, -s1);    // b=3,k1=3 : w^9
+        const v2 hh = {h, h};
+        const v2 w1 = {c1, s1}, w3 = {s1, c1}, w9 = {-c1, -s1};
+        x[1 + 4] = pk_cmul(x[1 + 4], w1);                 // b=1,k1=1 : w^1
+        x[1 + 8] = pk_add_i(x[1 + 8], x[1 + 8]) * hh;     // b=1,k1=2 : w^2 = (1+i) h
+        x[1 + 12] = pk_cmul(x[1 + 12], w3);               // b=1,k1=3 : w^3
+        x[2 + 4] = pk_add_i(x[2 + 4], x[2 + 4]) * hh;     // b=2,k1=1 : w^2
+        x[2 + 8] = pk_muli(x[2 + 8]);                     // b=2,k1=2 : w^4 = i
+        x[2 + 12] = pk_neg_add_i(x[2 + 12]) * hh;         // b=2,k1=3 : w^6 = (-1+i) h
+        x[3 + 4] = pk_cmul(x[3 + 4], w3);                 // b=3,k1=1 : w^3
+        x[3 + 8] = pk_neg_add_i(x[3 + 8]) * hh;           // b=3,k1=2 : w^6
+        x[3 + 12] = pk_cmul(x[3 + 12], w9);               // b=3,k1=3 : w^9
         // outer DFT4 over b for each k1; result k2 lands at index k1 + 4*k2
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1 + 0], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
@@ -117,7 +160,7 @@ template <> struct Dft<16> {
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) {
-                const c32 t = x[4 * p + q]; x[4 * p + q] = x[4 * q + p]; x[4 * q + p] = t;
+                const v2 t = x[4 * p + q]; x[4 * p + q] = x[4 * q + p]; x[4 * q + p] = t;
             }
     }
 };
@@ -126,27 +169,27 @@ template <> struct Dft<16> {
 // products deep for R = 16, ~2.4e-7 relative) and consumed as soon as they exist, so
 // only w1..w(R/2) stay live (not all R-1 powers).
 template <int R>
-__device__ __forceinline__ void apply_twiddles(c32 (&x)[R], c32 w1)
+__device__ __forceinline__ void apply_twiddles(v2 (&x)[R], v2 w1)
 {
     if constexpr (R == 2) {
-        x[1] = cmul(x[1], w1);
+        x[1] = pk_cmul(x[1], w1);
     } else if constexpr (R == 4) {
-        const c32 w2 = cmul(w1, w1);
-        x[1] = cmul(x[1], w1);
-        x[2] = cmul(x[2], w2);
-        x[3] = cmul(x[3], cmul(w1, w2));
+        const v2 w2 = pk_cmul(w1, w1);
+        x[1] = pk_cmul(x[1], w1);
+        x[2] = pk_cmul(x[2], w2);
+        x[3] = pk_cmul(x[3], pk_cmul(w1, w2));
     } else {
         constexpr int H = R / 2;
-        c32 pw[H + 1];
+        v2 pw[H + 1];
         pw[1] = w1;
-        x[1] = cmul(x[1], w1);
+        x[1] = pk_cmul(x[1], w1);
 #pragma unroll
         for (int i = 2; i <= H; ++i) {
-            pw[i] = cmul(pw[i / 2], pw[i - i / 2]);
-            x[i] = cmul(x[i], pw[i]);
+            pw[i] = pk_cmul(pw[i / 2], pw[i - i / 2]);
+            x[i] = pk_cmul(x[i], pw[i]);
         }
 #pragma unroll
-        for (int i = 1; i < H; ++i) x[H + i] = cmul(x[H + i], cmul(pw[H], pw[i]));
+        for (int i = 1; i < H; ++i) x[H + i] = pk_cmul(x[H + i], pk_cmul(pw[H], pw[i]));
     }
 }
 
@@ -250,6 +293,7 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
     constexpr int ITEMS = (N / R) * C;
     constexpr int IT = (ITEMS + T - 1) / T;
     constexpr bool GUARD = (ITEMS % T) != 0;
+    v2* ldsv = reinterpret_cast<v2*>(lds);
     if constexpr (LAST) {
         // nothing is written back to LDS: finish one work item at a time (R complex live, not IT*R)
 #pragma unroll
@@ -258,27 +302,27 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             if (!GUARD || w < ITEMS) {
                 int c, j;
                 last_stage_map<N, C, R>(w, c, j);
-                c32 x[R];
+                v2 x[R];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    if constexpr (FIRST) x[i] = in(j + i * (N / R), c, u, i);
-                    else x[i] = lds[lds_index<C>(j + i * (N / R), c)];
+                    if constexpr (FIRST) x[i] = tov(in(j + i * (N / R), c, u, i));
+                    else x[i] = ldsv[lds_index<C>(j + i * (N / R), c)];
                 }
 #ifndef OCEAN_ABL_NOFFT
-                if constexpr (NS > 1) apply_twiddles<R>(x, twr.w[STAGE][u]);
+                if constexpr (NS > 1) apply_twiddles<R>(x, tov(twr.w[STAGE][u]));
                 Dft<R>::run(x);
 #endif
                 const int k = j % NS;
                 const int j0 = (j - k) * R + k;
 #pragma unroll
-                for (int i = 0; i < R; ++i) out(j0 + i * NS, c, x[i], u, i);
+                for (int i = 0; i < R; ++i) out(j0 + i * NS, c, toc(x[i]), u, i);
             }
         }
         OCEAN_STAMP(8 + 3 * STAMP_BASE);
         OCEAN_STAMP(9 + 3 * STAMP_BASE);
         return;
     }
-    c32 x[IT][R];
+    v2 x[IT][R];
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
         const int w = tid + u * T;
@@ -286,11 +330,11 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             const int c = w % C, j = w / C;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                if constexpr (FIRST) x[u][i] = in(j + i * (N / R), c, u, i);
-                else x[u][i] = lds[lds_index<C>(j + i * (N / R), c)];
+                if constexpr (FIRST) x[u][i] = tov(in(j + i * (N / R), c, u, i));
+                else x[u][i] = ldsv[lds_index<C>(j + i * (N / R), c)];
             }
 #ifndef OCEAN_ABL_NOFFT
-            if constexpr (NS > 1) apply_twiddles<R>(x[u], twr.w[STAGE][u]);
+            if constexpr (NS > 1) apply_twiddles<R>(x[u], tov(twr.w[STAGE][u]));
             Dft<R>::run(x[u]);
 #endif
         }
@@ -306,7 +350,7 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             const int k = j % NS;
             const int j0 = (j - k) * R + k;
 #pragma unroll
-            for (int i = 0; i < R; ++i) lds[lds_index<C>(j0 + i * NS, c)] = x[u][i];
+            for (int i = 0; i < R; ++i) ldsv[lds_index<C>(j0 + i * NS, c)] = x[u][i];
         }
     }
 }

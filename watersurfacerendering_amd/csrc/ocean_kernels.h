@@ -54,7 +54,11 @@ __device__ __forceinline__ void store_map(float4* p, float4 v, int streaming)
     if (streaming) store_nt(p, v);
     else *p = v;
 }
+#ifdef OCEAN_ABL_NOMAPSTORE      // ablation build: the map texels are computed but never written
+#define OCEAN_STORE(ptr, val) do { const float4 v_ = (val); asm volatile("" ::"v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w)); } while (0)
+#else
 #define OCEAN_STORE(ptr, val) store_map((ptr), (val), a.stream_maps)
+#endif
 
 struct TileParams {          // device copy of one tile's properties
     float wind_x, wind_y;    // unit vector (SetWindDirection, .cpp:476-479)
@@ -897,6 +901,8 @@ OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
 OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, OCEAN_R(8, 8, 8, 4))
 #elif defined(OCEAN_V_D)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
+#elif defined(OCEAN_V_E)
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 2, 512, OCEAN_R(8, 8, 8, 4))
 #elif defined(OCEAN_V_X1)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, OCEAN_R(8, 16, 16))
 #elif defined(OCEAN_V_X2)
