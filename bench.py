@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=2048, help="tile size N (default: the roofline config, 2048)")
     ap.add_argument("--tiles", type=int, default=1, help="independent tiles per rank per step")
-    ap.add_argument("--depth", type=int, default=2, help="frame pipeline depth of the asynchronous API (1 = strictly serial frames)")
+    ap.add_argument("--depth", type=int, default=3, help="frame pipeline depth of the asynchronous API (1 = strictly serial frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather measurement at N>1")

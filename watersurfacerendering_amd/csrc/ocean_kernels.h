@@ -399,8 +399,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifndef OCEAN_ZPASS_MINW
 #define OCEAN_ZPASS_MINW 1
 #endif
+// minimum waves per SIMD asked of the register allocator: 2048 fits 80 VGPRs without a
+// spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
+// 1024 and 4096 would spill at that cap and keep the looser one
+template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : OCEAN_ZPASS_MINW); }
 template <int N, int T, class P = Plan<N>, bool H16 = false>
-__global__ void __launch_bounds__(T, (N >= 1024 ? 3 : OCEAN_ZPASS_MINW)) k_zpass(const FrameArgs a)
+__global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // 2 interleaved transforms
