@@ -1,5 +1,4 @@
-bash tools/ab.sh "default z6 xb4 z6xb4" 2048 1 1,2,3
-for L in default z6 xb4; do
-  if [ "$L" = "default" ]; then unset OCEAN_HIP_LIB; else export OCEAN_HIP_LIB=watersurfacerendering_amd/libocean_hip_$L.so; fi
-  echo -n "[$L] "; python tools/quick_bench.py 2048 | grep -o "kernels.*"
-done
+python -m pytest tests/test_parity_gpu.py -x -q -m gpu 2>&1 | tail -2
+python tools/quick_bench.py 512,1024,2048,4096
+for r in 1 2 3; do python tools/depth_batch.py 2048 1 1,2,3; done
+python tools/depth_batch.py 512 16 1,2

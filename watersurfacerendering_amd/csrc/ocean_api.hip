@@ -368,7 +368,7 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st, hipEvent_t wait_before_cols,
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, bool stream_maps, hipStream_t st, hipEvent_t wait_before_cols,
                                hipEvent_t* marks /* 4 events or null */)
 {
     using G = Geo<N>;
@@ -389,10 +389,13 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true>, lds_rows)) != hipSuccess) return e;
         if constexpr (G::MERGED) {
             if ((e = allow_lds(k_xpass_height<N, CH, G::T_H, typename G::PC>, lds_h)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
         } else {
-            if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC>, lds_b)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC>, lds_m)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false>, lds_b)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
+            if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
         }
         attr_done = true;
     }
@@ -431,15 +434,18 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, hipStream_t st,
 #ifdef OCEAN_STAMPS
         arm(2);
 #endif
-        hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+        if (stream_maps) hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+        else hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
     } else {
         if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
+        if (stream_maps) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
+        else hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, false>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
         if (marks) (void)hipEventRecord(marks[2], st);
 #ifdef OCEAN_STAMPS
         arm(2);
 #endif
-        hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+        if (stream_maps) hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+        else hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
     }
     if (marks) (void)hipEventRecord(marks[3], st);
     return hipGetLastError();
@@ -477,20 +483,20 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.t = t;
     a.mode = c->mode;
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
-    a.stream_maps = (c->n >= 4096 || pipe) ? 1 : 0;
+    bool stream_maps = c->n >= 4096 || pipe;
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs)
-    if (stream_env) a.stream_maps = atoi(stream_env);
+    if (stream_env) stream_maps = atoi(stream_env) != 0;
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
-        case 16: e = launch_frame<16>(c, a, st, wait, marks); break;
-        case 32: e = launch_frame<32>(c, a, st, wait, marks); break;
-        case 64: e = launch_frame<64>(c, a, st, wait, marks); break;
-        case 128: e = launch_frame<128>(c, a, st, wait, marks); break;
-        case 256: e = launch_frame<256>(c, a, st, wait, marks); break;
-        case 512: e = launch_frame<512>(c, a, st, wait, marks); break;
-        case 1024: e = launch_frame<1024>(c, a, st, wait, marks); break;
-        case 2048: e = launch_frame<2048>(c, a, st, wait, marks); break;
-        case 4096: e = launch_frame<4096>(c, a, st, wait, marks); break;
+        case 16: e = launch_frame<16>(c, a, stream_maps, st, wait, marks); break;
+        case 32: e = launch_frame<32>(c, a, stream_maps, st, wait, marks); break;
+        case 64: e = launch_frame<64>(c, a, stream_maps, st, wait, marks); break;
+        case 128: e = launch_frame<128>(c, a, stream_maps, st, wait, marks); break;
+        case 256: e = launch_frame<256>(c, a, stream_maps, st, wait, marks); break;
+        case 512: e = launch_frame<512>(c, a, stream_maps, st, wait, marks); break;
+        case 1024: e = launch_frame<1024>(c, a, stream_maps, st, wait, marks); break;
+        case 2048: e = launch_frame<2048>(c, a, stream_maps, st, wait, marks); break;
+        case 4096: e = launch_frame<4096>(c, a, stream_maps, st, wait, marks); break;
         default: return OCEAN_E_UNSUPPORTED;
     }
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }

@@ -48,17 +48,20 @@ __device__ __forceinline__ void store_nt(float4* p, float4 v)
 // memory-side cache: when several frames are in flight a non-temporal map store keeps the
 // output stream from evicting that resident set (2048^2, depth 2: -8 % frame time).  A lone
 // serial frame prefers plain stores (the cache then buffers the write burst: +6 % with
-// non-temporal), so the host picks per launch (FrameArgs::stream_maps).
-__device__ __forceinline__ void store_map(float4* p, float4 v, int streaming)
+// non-temporal), so the x-pass kernels exist in both forms (template flag NTS) and the host
+// picks per launch.  The texel index is turned into a 32-bit byte offset (N <= 4096: < 2^28)
+// so the store addresses as scalar base + vector offset.
+template <bool NTS> __device__ __forceinline__ void store_map(float4* base, unsigned texel, float4 v)
 {
-    if (streaming) store_nt(p, v);
-    else *p = v;
-}
 #ifdef OCEAN_ABL_NOMAPSTORE      // ablation build: the map texels are computed but never written
-#define OCEAN_STORE(ptr, val) do { const float4 v_ = (val); asm volatile("" ::"v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w)); } while (0)
+    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #else
-#define OCEAN_STORE(ptr, val) store_map((ptr), (val), a.stream_maps)
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + (texel * 16u));
+    if constexpr (NTS) store_nt(p, v);
+    else *p = v;
 #endif
+}
+#define OCEAN_STORE(base, texel, val) store_map<NTS>((base), (unsigned)(texel), (val))
 
 struct TileParams {          // device copy of one tile's properties
     float wind_x, wind_y;    // unit vector (SetWindDirection, .cpp:476-479)
@@ -89,7 +92,6 @@ struct FrameArgs {
     const float* lambda;     // [tiles]
     float t;
     int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only)
-    int stream_maps;         // 1 = write the maps with non-temporal stores (see store_map)
 };
 
 
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(T) k_xpass_height(const FrameArgs a)
 //     load p0, p1 | FFT p0 -> store displacement | load p2 | FFT p1 (held) | FFT p2 -> store normal
 // NormalizeHeights (.cpp:443-455) is folded into the displacement store.
 // ============================================================================
-template <int N, int C, int T, class P = Plan<N>>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
 __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -664,9 +666,9 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 #ifdef OCEAN_ABL_NOSTORE
         asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z)); if (p >= 0) return;
 #endif
-        OCEAN_STORE(&disp[(unsigned)(q * N + p)], o);                // texel (row q, column p)
+        OCEAN_STORE(disp, q * N + p, o);                // texel (row q, column p)
         if (q != 0 && q != N / 2)                                    // mirror: Dx, Dz odd, height even
-            OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
+            OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, 1.0f));
     };
     auto emit_nrm = [&](int p, int c, c32 slopes, c32 derivs) {
         const int q = u0 + c;
@@ -677,9 +679,9 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 #ifdef OCEAN_ABL_NOSTORE
         asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); if (p >= 0) return;
 #endif
-        OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
+        OCEAN_STORE(nrm, q * N + p, o);
         if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-            OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
+            OCEAN_STORE(nrm, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, -o.y, o.z, o.w));
     };
     const c32 zero = make_float2(0.0f, 0.0f);
     if (a.mode == 2) {               // HEIGHT1: height only, no transforms in this pass
@@ -723,7 +725,7 @@ __global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
 #ifndef OCEAN_XB_MINW
 #define OCEAN_XB_MINW 1
 #endif
-template <int N, int C, int T, class P = Plan<N>>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
 __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -790,9 +792,9 @@ __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
         // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
         const float4 o = make_float4(s * slopes.x, s * slopes.y, s * derivs.x, s * derivs.y);
-        OCEAN_STORE(&nrm[(unsigned)(q * N + p)], o);
+        OCEAN_STORE(nrm, q * N + p, o);
         if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-            OCEAN_STORE(&nrm[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, -o.y, o.z, o.w));
+            OCEAN_STORE(nrm, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, -o.y, o.z, o.w));
     };
     const c32 zero = make_float2(0.0f, 0.0f);
     if (a.mode == 2) {               // HEIGHT1: the normal map is all zero
@@ -821,7 +823,7 @@ __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
 #ifndef OCEAN_XD_MINW
 #define OCEAN_XD_MINW 1
 #endif
-template <int N, int C, int T, class P = Plan<N>>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
 __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -858,9 +860,9 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
         if (q > N / 2) return;
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
         const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
-        OCEAN_STORE(&disp[(unsigned)(q * N + p)], o);
+        OCEAN_STORE(disp, q * N + p, o);
         if (q != 0 && q != N / 2)
-            OCEAN_STORE(&disp[(unsigned)((N - q) * N + ((N - p) & (N - 1)))], make_float4(-o.x, o.y, -o.z, 1.0f));
+            OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, 1.0f));
     };
     if (a.mode == 2) {               // HEIGHT1: no horizontal displacement, no transform
         for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
