@@ -46,8 +46,8 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 #    symmetry): 108 B/texel per frame, apportioned to the launches that do that work;
 #    `roofline.achieved` uses this one, as the task statement prescribes.
 #  * what this pipeline actually has to move (half-size intermediates): 76 B/texel per frame.
-KERNEL_BYTES_SURVEY = {"k_zpass": 40, "k_xpass_b": 40, "k_xpass_disp": 28, "k_xpass_height": 8, "k_xpass_maps": 60}
-KERNEL_BYTES_ACTUAL = {"k_zpass": 26, "k_xpass_b": 28, "k_xpass_disp": 22, "k_xpass_height": 4, "k_xpass_maps": 46}
+KERNEL_BYTES_SURVEY = {"k_zpass": 40, "k_xpass_b": 40, "k_xpass_disp": 28}
+KERNEL_BYTES_ACTUAL = {"k_zpass": 26, "k_xpass_b": 28, "k_xpass_disp": 22}
 FRAME_BYTES_SURVEY = 108.0
 
 

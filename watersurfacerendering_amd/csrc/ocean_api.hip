@@ -352,8 +352,8 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
 template <int N> static const char* kernel_name_of(int idx)
 {
     if (idx == 0) return "k_zpass";
-    if (idx == 1) return Geo<N>::MERGED ? "k_xpass_height" : "k_xpass_b";
-    if (idx == 2) return Geo<N>::MERGED ? "k_xpass_maps" : "k_xpass_disp";
+    if (idx == 1) return "k_xpass_b";
+    if (idx == 2) return "k_xpass_disp";
     return nullptr;
 }
 
@@ -375,28 +375,21 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, bool stream_map
     using HF = Half<N>;
     const unsigned tiles = c->tiles;
     hipError_t e;
-    constexpr int C = G::CC, CH = G::CH;
+    constexpr int C = G::CC;
     constexpr size_t lds_rows = zpass_lds_bytes<N>();
-    constexpr size_t lds_h = sizeof(c32) * fft_lds_elems<N, CH>() + sizeof(float) * 2 * ((G::T_H + 63) / 64);
     constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
-    static_assert(HF::NUP % (2 * CH) == 0 && HF::NUP % (2 * C) == 0, "height row blocks");
-    constexpr unsigned hb = HF::NUP / (2 * CH), hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
+    static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
+    constexpr unsigned hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
     static bool attr_done_dev[64] = {};             // function attributes are per device
     bool& attr_done = attr_done_dev[c->device & 63];
     if (!attr_done) {
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true>, lds_rows)) != hipSuccess) return e;
-        if constexpr (G::MERGED) {
-            if ((e = allow_lds(k_xpass_height<N, CH, G::T_H, typename G::PC>, lds_h)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_maps<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
-        } else {
-            if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false>, lds_b)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
-            if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
-        }
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
         attr_done = true;
     }
 #ifdef OCEAN_STAMPS
@@ -425,28 +418,15 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, bool stream_map
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
     arm(1);
 #endif
-    // the maps are shared by all frames: this frame may only start writing them
-    // once the previous frame (other stream) has finished its own
-    if constexpr (G::MERGED) {
-        hipLaunchKernelGGL((k_xpass_height<N, CH, G::T_H, typename G::PC>), dim3(hb, tiles), dim3(G::T_H), lds_h, st, a);
-        if (marks) (void)hipEventRecord(marks[2], st);
-        if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
+    if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
+    if (stream_maps) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
+    else hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, false>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
+    if (marks) (void)hipEventRecord(marks[2], st);
 #ifdef OCEAN_STAMPS
-        arm(2);
+    arm(2);
 #endif
-        if (stream_maps) hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
-        else hipLaunchKernelGGL((k_xpass_maps<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
-    } else {
-        if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
-        if (stream_maps) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
-        else hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, false>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
-        if (marks) (void)hipEventRecord(marks[2], st);
-#ifdef OCEAN_STAMPS
-        arm(2);
-#endif
-        if (stream_maps) hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
-        else hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
-    }
+    if (stream_maps) hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+    else hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
     if (marks) (void)hipEventRecord(marks[3], st);
     return hipGetLastError();
 }

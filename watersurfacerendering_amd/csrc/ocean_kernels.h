@@ -542,185 +542,16 @@ __device__ __forceinline__ void for_each_output(int tid, F f)
 }
 
 // ============================================================================
-// k_xpass_height: 2*C rows of the height per workgroup (C transforms of two real
-// rows each: Y_u + i Y_{u+1}), sign, raw signed height out, global min/max.
-// ============================================================================
-template <int N, int C, int T, class P = Plan<N>>
-__global__ void __launch_bounds__(T) k_xpass_height(const FrameArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using HF = Half<N>;
-    c32* fbuf = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.y;
-    TwiddleRegs<N, C, T, P> twr;
-    twr.load(a.tw, tid);
-    constexpr int NW = (T + 63) / 64;
-    float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
-    const int u0 = xcd_swizzle(blockIdx.x, HF::NUP / (2 * C)) * 2 * C;
-    const float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE;
-    float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
-    float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
-    // Y_u(nf) = Zh(nf,u), nf <= N/2; conj Zh(N-nf,u) above (real, even spectrum);
-    // entries 0 and N/2 are real.  Two rows u, u+1 per transform: Y_u + i Y_{u+1}.
-    auto in = [&](int nf, int c, int, int) -> c32 {
-        const int row = nf <= N / 2 ? nf : N - nf;
-        const float4 z = *reinterpret_cast<const float4*>(zh + (unsigned)(row * HF::NUP + u0 + 2 * c));
-        if (nf == 0 || nf == N / 2) return make_float2(z.x, z.z);
-        if (nf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
-        return make_float2(z.x + z.w, z.z - z.y);
-    };
-    auto out = [&](int p, int c, c32 v, int, int) {
-        const int u = u0 + 2 * c;
-        const float s = ((p + u) & 1) ? -1.0f : 1.0f;              // .cpp:388-390
-        const float ha = s * v.x, hb = -s * v.y;
-        if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
-        if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
-        *reinterpret_cast<float2*>(hraw + hraw_index(N, p, u)) = make_float2(ha, hb);
-    };
-    batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
-    // workgroup reduction -> one atomic pair (.cpp:391-392, 407-411)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        vmin = fminf(vmin, __shfl_xor(vmin, o));
-        vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    }
-    if ((tid & 63) == 0) { red[tid >> 6] = vmin; red[NW + (tid >> 6)] = vmax; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < NW; ++w) { vmin = fminf(vmin, red[w]); vmax = fmaxf(vmax, red[NW + w]); }
-        atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
-        atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
-    }
-}
-
-// ============================================================================
-// k_xpass_maps: C output rows (units u0..u0+C-1) of BOTH maps per workgroup, and
-// their mirror rows.  Three transforms per workgroup (pairs 0, 1, 2); the inputs
-// of the next transform are fetched into registers while the current one runs,
-// and the displacement rows stream out while pairs 1 and 2 are transformed:
-//     load p0, p1 | FFT p0 -> store displacement | load p2 | FFT p1 (held) | FFT p2 -> store normal
-// NormalizeHeights (.cpp:443-455) is folded into the displacement store.
-// ============================================================================
-template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
-__global__ void __launch_bounds__(T) k_xpass_maps(const FrameArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using HF = Half<N>;
-    using FS = FirstStage<N, C, T, P>;
-    using LS = LastStage<N, C, T, P>;
-    c32* fbuf = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.y;
-    constexpr int NB = (HF::NU + C - 1) / C;
-    const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
-    const float2* __restrict__ z0 = a.z + (size_t)tile * HF::Z_TILE;
-    const float2* __restrict__ z1 = z0 + HF::Z_GROUP;
-    const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
-    const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
-    float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
-    float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
-    OCEAN_STAMP(0);
-    TwiddleRegs<N, C, T, P> twr;
-    twr.load(a.tw, tid);
-
-    // first-stage inputs of one pair for this thread's work items
-    auto fetch = [&](const float2* __restrict__ zg, float eps, c32 (&dst)[FS::IT][FS::R0]) {
-#pragma unroll
-        for (int u = 0; u < FS::IT; ++u) {
-            const int w = tid + u * T;
-            if (!FS::GUARD || w < FS::ITEMS) {
-                const int c = w % C, j = w / C;
-#pragma unroll
-                for (int i = 0; i < FS::R0; ++i) dst[u][i] = load_pair_column<N>(zg, j + i * FS::STRIDE, u0 + c, eps);
-            }
-        }
-    };
-    c32 xa[FS::IT][FS::R0], xb[FS::IT][FS::R0];
-    fetch(z0, -1.0f, xa);
-    fetch(z1, -1.0f, xb);
-    // raw heights of the texels this thread will finish
-    float hv[LS::IT][LS::RL];
-#pragma unroll
-    for (int u = 0; u < LS::IT; ++u) {
-        const int w = tid + u * T;
-        if (!LS::GUARD || w < LS::ITEMS) {
-            int c, j;
-            LS::map(w, c, j);
-#pragma unroll
-            for (int i = 0; i < LS::RL; ++i) hv[u][i] = hraw[hraw_index(N, j + i * LS::STRIDE, u0 + c)];
-        }
-    }
-    // A = max(|min|, |max|), y *= 1/A
-    const float mn = key_float(a.minmax[2 * tile + 0]);
-    const float mx = key_float(a.minmax[2 * tile + 1]);
-    const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
-    const float lambda = a.lambda[tile];
-
-    auto emit_disp = [&](int p, int c, c32 v, int u, int i) {
-        const int q = u0 + c;
-        if (q > N / 2) return;                                       // padding row
-        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-        // (sign*lambda)*Re Dx, h/A, (sign*lambda)*Re Dz, 1   (.cpp:394-403)
-        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
-#ifdef OCEAN_ABL_NOSTORE
-        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z)); if (p >= 0) return;
-#endif
-        OCEAN_STORE(disp, q * N + p, o);                // texel (row q, column p)
-        if (q != 0 && q != N / 2)                                    // mirror: Dx, Dz odd, height even
-            OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, 1.0f));
-    };
-    auto emit_nrm = [&](int p, int c, c32 slopes, c32 derivs) {
-        const int q = u0 + c;
-        if (q > N / 2) return;
-        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-        // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
-        const float4 o = make_float4(s * slopes.x, s * slopes.y, s * derivs.x, s * derivs.y);
-#ifdef OCEAN_ABL_NOSTORE
-        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); if (p >= 0) return;
-#endif
-        OCEAN_STORE(nrm, q * N + p, o);
-        if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
-            OCEAN_STORE(nrm, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, -o.y, o.z, o.w));
-    };
-    const c32 zero = make_float2(0.0f, 0.0f);
-    if (a.mode == 2) {               // HEIGHT1: height only, no transforms in this pass
-        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { emit_disp(p, c, zero, u, i); emit_nrm(p, c, zero, zero); });
-        return;
-    }
-    // ---- pair 0 -> displacement map -----------------------------------------------
-    {
-        auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
-        batch_fft<N, C, T, P>(fbuf, twr, tid, in, emit_disp);
-    }
-    OCEAN_STAMP(1);
-    if (a.mode == 0) fetch(z2, 1.0f, xa);        // pair 2 inputs travel while pair 1 is transformed
-    // ---- pairs 1 and 2 -> normal map -----------------------------------------------
-    c32 held[LS::IT][LS::RL];
-    {
-        auto in = [&](int, int, int u, int i) -> c32 { return xb[u][i]; };
-        auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
-        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
-    }
-    OCEAN_STAMP(2);
-    if (a.mode == 1) {               // CHOPPY5: slopes only
-        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { emit_nrm(p, c, held[u][i], zero); });
-        return;
-    }
-    {
-        auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
-        auto out = [&](int p, int c, c32 v, int u, int i) { emit_nrm(p, c, held[u][i], v); };
-        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
-    }
-    OCEAN_STAMP(3);
-}
-
-// ============================================================================
-// Split x pass (used where one round of workgroups covers the tile, N <= 2048):
-//   k_xpass_b    blockIdx.x < HB  -> HEIGHT workgroup (as k_xpass_height)
-//                otherwise        -> NORMAL workgroup: pairs 1 and 2 -> normal map
-//   k_xpass_disp pair 0 + raw height -> displacement map (needs the min/max)
-// The height transforms then run beside the normal-map ones instead of alone.
+// x pass (second pass, x axis), two launches:
+//   k_xpass_b    blockIdx.x < HB  -> HEIGHT workgroup: 2*C rows of the height (C transforms of
+//                                    two real rows each: Y_u + i Y_{u+1}), sign, raw signed
+//                                    height out, global min/max
+//                otherwise        -> NORMAL workgroup: pairs 1 and 2 -> normal-map rows
+//   k_xpass_disp pair 0 + raw height -> displacement-map rows (needs the min/max);
+//                NormalizeHeights (.cpp:443-455) is folded into the store
+// The height transforms run beside the normal-map ones instead of alone.  (A merged form --
+// one height launch, then all three pairs per workgroup with register prefetch -- was
+// measured slower at every size and removed.)
 // ============================================================================
 #ifndef OCEAN_XB_MINW
 #define OCEAN_XB_MINW 1
@@ -874,56 +705,23 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
 #define OCEAN_R(...) Radices<__VA_ARGS__>
-#define OCEAN_GEO(n, tr, pr, merged, ch, th, cc, tc, pc)                                        \
+#define OCEAN_GEO(n, tr, pr, cc, tc, pc)                                                       \
     template <> struct Geo<n> {                                                                \
         static constexpr int T_ROWS = tr;               /* threads of k_zpass               */ \
-        static constexpr bool MERGED = merged;          /* x pass: height + maps | b + disp */ \
-        static constexpr int CH = ch, T_H = th;         /* k_xpass_height: transforms, threads */ \
-        static constexpr int CC = cc, T_C = tc;         /* maps / b / disp: rows, threads   */ \
-        using PR = pr; using PC = pc;                   /* radix plans                      */ \
+        static constexpr int CC = cc, T_C = tc;         /* x pass: rows per workgroup, threads */ \
+        using PR = pr; using PC = pc;                   /* radix plans: z pass, x pass      */ \
     };
-OCEAN_GEO(16, 64, Plan<16>, false, 4, 64, 4, 64, Plan<16>)
-OCEAN_GEO(32, 64, Plan<32>, false, 4, 64, 4, 64, Plan<32>)
-OCEAN_GEO(64, 64, Plan<64>, false, 4, 64, 4, 64, Plan<64>)
-OCEAN_GEO(128, 64, Plan<128>, false, 4, 64, 4, 64, Plan<128>)
-OCEAN_GEO(256, 64, Plan<256>, false, 4, 64, 4, 64, Plan<256>)
-OCEAN_GEO(512, 128, Plan<512>, false, 2, 128, 4, 256, Plan<512>)
-#if defined(OCEAN_V_R16)
-OCEAN_GEO(1024, 128, Plan<1024>, false, 2, 128, 4, 256, Plan<1024>)
-#else
-OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), false, 2, 128, 4, 256, Plan<1024>)     // radix-8 z pass: -9 %
-#endif
-#if defined(OCEAN_V_S2)
-OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 2, 256, Plan<2048>)
-#elif defined(OCEAN_V_M)
-OCEAN_GEO(2048, 256, Plan<2048>, true, 2, 256, 4, 512, Plan<2048>)
-#elif defined(OCEAN_V_M2)
-OCEAN_GEO(2048, 256, Plan<2048>, true, 2, 256, 2, 256, Plan<2048>)
-#elif defined(OCEAN_V_A)
-OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, Plan<2048>)
-#elif defined(OCEAN_V_B)
-OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
-#elif defined(OCEAN_V_C)
-OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, OCEAN_R(8, 8, 8, 4))
-#elif defined(OCEAN_V_D)
-OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 1024, OCEAN_R(8, 8, 8, 4))
-#elif defined(OCEAN_V_E)
-OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 2, 512, OCEAN_R(8, 8, 8, 4))
-#elif defined(OCEAN_V_X1)
-OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, OCEAN_R(8, 16, 16))
-#elif defined(OCEAN_V_X2)
-OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, OCEAN_R(16, 8, 16))
-#elif defined(OCEAN_V_R16)
-OCEAN_GEO(2048, 256, Plan<2048>, false, 2, 256, 4, 512, Plan<2048>)
-#else
-// z pass on radix-8 butterflies with 512 threads (100 VGPRs, 4 waves/SIMD): ~1.5 % faster than radix 16 / 256 threads
-OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), false, 2, 256, 4, 512, Plan<2048>)
-#endif
-#if defined(OCEAN_V_R16)
-OCEAN_GEO(4096, 512, Plan<4096>, true, 2, 512, 2, 512, Plan<4096>)
-#else
-OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), true, 2, 512, 2, 512, Plan<4096>)    // radix-8 z pass: -4.5 %
-#endif
+OCEAN_GEO(16, 64, Plan<16>, 4, 64, Plan<16>)
+OCEAN_GEO(32, 64, Plan<32>, 4, 64, Plan<32>)
+OCEAN_GEO(64, 64, Plan<64>, 4, 64, Plan<64>)
+OCEAN_GEO(128, 64, Plan<128>, 4, 64, Plan<128>)
+OCEAN_GEO(256, 64, Plan<256>, 4, 64, Plan<256>)
+OCEAN_GEO(512, 128, Plan<512>, 4, 256, Plan<512>)
+// from 1024 up the z pass runs radix-8 butterflies with twice the threads (one more LDS
+// exchange, about half the VGPRs): -9 % at 1024, -1.5 % at 2048, -4.5 % at 4096
+OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), 4, 256, Plan<1024>)
+OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), 4, 512, Plan<2048>)
+OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), 2, 512, Plan<4096>)
 #undef OCEAN_GEO
 
 }  // namespace ocean
