@@ -12,12 +12,12 @@ omega) are resident in HBM before the timed region; outputs are the two finished
 RGBA32F maps in HBM (D2H read-back is not part of the metric).
 
 The K timed steps are K asynchronous ocean_compute_waves_async calls followed by one
-synchronise.  With --depth 2 (default) consecutive frames alternate between two
+synchronise.  With --depth 3 (default) consecutive frames rotate over three
 independent chains (own stream, own intermediates, own map set), so one frame's first
-pass overlaps the other's map passes; every frame is still computed in full and its
+pass overlaps the others' map passes; every frame is still computed in full and its
 maps stay addressable until the chain is reused.  --depth 1 = strictly serial frames
 (also reported under extra).  Per-launch durations for the roofline object come from HIP
-events around every launch in the same regime (a second pass of the same frames).
+events around every launch of serial frames (a second pass of the same frames).
 
 Multi-GPU: tiles are independent, so every rank synthesises its own tile(s)
 with no data-path collective ("weak" scaling, value = frames of all ranks per
