@@ -252,7 +252,8 @@ def main():
             b.compute_waves_async(DT * j)
             b.synchronize()
             wdist.gather_maps(maps if backend == "nccl" else maps.cpu(), dst=0)
-        torch.cuda.synchronize(); barrier()
+            torch.cuda.synchronize()          # the collective runs on its own stream: finish it before `maps` is rewritten
+        barrier()
         serial = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
         # the same with the gather of frame j-1 overlapped with the synthesis of frame j (two map sets,
         # the collective on its own stream): SURVEY.md 8e's third figure
@@ -271,7 +272,8 @@ def main():
             b.synchronize()
             if work is not None:
                 work.wait()
-        torch.cuda.synchronize(); barrier()
+                torch.cuda.synchronize()      # host-side completion: the next frame reuses that map set
+        barrier()
         overlapped = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
         gather = {"what": "every step followed by one torch.distributed.gather (RCCL) of the packed maps to rank 0; "
                           "'overlapped' = the gather of frame j-1 runs beside the synthesis of frame j (two map sets)",
