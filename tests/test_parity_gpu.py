@@ -69,6 +69,18 @@ def test_maps_match_oracle_defaults(n):
     b.close()
 
 
+@pytest.mark.parametrize("n", [64, 512])
+def test_negative_and_very_large_times(n):
+    """omega*t beyond the fast range reduction (|x| >= 1e5 rad takes the library sincos path), and t < 0."""
+    from oracle import oracle as O
+    xi = O.gauss_xi_numpy(4321, n)
+    o = make_oracle(n, xi)
+    b = make_gpu(n, xi[None])
+    for t in (-3.25, 9.0e3, 5.0e4, 3.0e5, 2.5e6):
+        check_frame(b, o, t)
+    b.close()
+
+
 @pytest.mark.parametrize("n", [16, 64, 256, 512])
 def test_maps_match_oracle_alt_params(n):
     from oracle import oracle as O
