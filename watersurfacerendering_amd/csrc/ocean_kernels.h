@@ -632,7 +632,32 @@ __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
         for_each_output<LS, T>(tid, [&](int p, int c, int, int) { emit(p, c, zero, zero); });
         return;
     }
-    {
+    // From 2048 up this role runs one workgroup per CU whatever it does below 256 VGPRs, so the
+    // inputs of the second transform are fetched into registers right behind those of the
+    // first and travel while the first is computed.  Below that the registers are worth more
+    // as a second workgroup per CU.
+    constexpr bool PREFETCH = N >= 2048;
+    using FS = FirstStage<N, C, T, P>;
+    [[maybe_unused]] c32 xb[PREFETCH ? FS::IT : 1][PREFETCH ? FS::R0 : 1];
+    auto fetch = [&](const float2* __restrict__ zg, float eps, auto& dst) {
+#pragma unroll
+        for (int u = 0; u < FS::IT; ++u) {
+            const int w = tid + u * T;
+            if (!FS::GUARD || w < FS::ITEMS) {
+                const int c = w % C, j = w / C;
+#pragma unroll
+                for (int i = 0; i < FS::R0; ++i) dst[u][i] = load_pair_column<N>(zg, j + i * FS::STRIDE, u0 + c, eps);
+            }
+        }
+    };
+    if constexpr (PREFETCH) {
+        c32 xa[FS::IT][FS::R0];
+        fetch(z1, -1.0f, xa);
+        if (a.mode == 0) fetch(z2, 1.0f, xb);
+        auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
+        auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    } else {
         auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z1, nf, u0 + c, -1.0f); };
         auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
@@ -641,10 +666,14 @@ __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
         for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { emit(p, c, held[u][i], zero); });
         return;
     }
-    // keep the second transform's loads from being hoisted over the first one's last
-    // stage: that costs ~45 VGPRs and with them the second workgroup per CU
-    __builtin_amdgcn_sched_barrier(0);
-    {
+    if constexpr (PREFETCH) {
+        auto in = [&](int, int, int u, int i) -> c32 { return xb[u][i]; };
+        auto out = [&](int p, int c, c32 v, int u, int i) { emit(p, c, held[u][i], v); };
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    } else {
+        // keep the second transform's loads from being hoisted over the first one's last
+        // stage: that costs ~45 VGPRs and with them the second workgroup per CU
+        __builtin_amdgcn_sched_barrier(0);
         auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z2, nf, u0 + c, 1.0f); };
         auto out = [&](int p, int c, c32 v, int u, int i) { emit(p, c, held[u][i], v); };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
