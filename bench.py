@@ -135,6 +135,23 @@ def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1, mode
             "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern)}}
 
 
+def measure_sync_calls(W, n, device, calls=300):
+    """Median latency of the synchronous ComputeWaves (the reference's call shape: returns the amplitude)."""
+    import numpy as np
+    b = W.OceanBatch(n, 1, device)
+    b.prepare(SEED)
+    for j in range(30):
+        b.compute_waves(DT * j)
+    ts = np.empty(calls)
+    for j in range(calls):
+        t0 = time.perf_counter()
+        b.compute_waves(DT * j)
+        ts[j] = time.perf_counter() - t0
+    b.close()
+    return {"size": n, "calls": calls, "median_us_per_call": float(np.median(ts) * 1e6), "p95_us_per_call": float(np.percentile(ts, 95) * 1e6),
+            "what": "host-side wall time of ocean_compute_waves (enqueue + the frame + one stream synchronisation; min/max keys arrive in host-coherent memory), called from Python"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -294,6 +311,8 @@ def main():
             extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 300, 20, depth=4)
             extra["512x512_choppy5_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20, mode=1)
             extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 300, 20, mode=2)
+            extra["512x512_synchronous_calls"] = measure_sync_calls(W, 512, local_rank)
+            extra["2048x2048_synchronous_calls"] = measure_sync_calls(W, 2048, local_rank)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
             extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 100, 10, depth=2)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)

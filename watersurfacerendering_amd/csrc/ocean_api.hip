@@ -55,6 +55,7 @@ struct ocean_ctx {
     float2* zh[MAXD] = {};
     float* hraw[MAXD] = {};
     unsigned* minmax[MAXD] = {};
+    unsigned* mm_host[MAXD] = {};   // pinned, device-visible copy of minmax written by the last kernel of a frame
     float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
     float4* nrmN[MAXD] = {};
     float4* ext_disp = nullptr;
@@ -84,8 +85,9 @@ static void free_device(ocean_ctx* c)
     for (int i = 0; i < MAXD; ++i) {
         void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
         for (void* b : per) if (b) (void)hipFree(b);
+        if (c->mm_host[i]) (void)hipHostFree(c->mm_host[i]);
         c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr;
-        c->dispN[i] = nullptr; c->nrmN[i] = nullptr;
+        c->dispN[i] = nullptr; c->nrmN[i] = nullptr; c->mm_host[i] = nullptr;
     }
     c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr;
     c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
@@ -107,6 +109,9 @@ static int alloc_set(ocean_ctx* c, int i)
     HIP_TRY(hipMemset(c->zh[i], 0, t * nu * nup * sizeof(float2)));
     HIP_TRY(hipMemset(c->hraw[i], 0, t * nup * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
+    // the displacement pass also drops the final min/max keys into this host-coherent buffer, so the
+    // synchronous ComputeWaves needs one stream synchronisation and no device-to-host copy
+    HIP_TRY(hipHostMalloc((void**)&c->mm_host[i], t * 2 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipMalloc(&c->dispN[i], t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->nrmN[i], t * n2 * sizeof(float4)));
     return OCEAN_OK;
@@ -456,6 +461,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
+    a.minmax_host = c->mm_host[set];
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
     a.toff = c->use_toff ? c->toff : nullptr;
@@ -502,10 +508,13 @@ int ocean_synchronize(ocean_t* c)
     return OCEAN_OK;
 }
 
-static int fetch_minmax(ocean_ctx* c)
+static int fetch_minmax(ocean_ctx* c, bool only_last_chain = false)
 {
-    SYNC_ALL(c);
-    HIP_TRY(hipMemcpy(c->h_minmax, c->minmax[c->last_set], c->tiles * 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    // the keys of the last frame are in host-coherent memory once its stream has drained
+    if (only_last_chain) HIP_TRY(hipStreamSynchronize(stream_of(c, c->last_set)));
+    else SYNC_ALL(c);
+    if (!c->mm_host[c->last_set]) return OCEAN_E_NOT_READY;
+    std::memcpy(c->h_minmax, c->mm_host[c->last_set], c->tiles * 2 * sizeof(unsigned));
     return OCEAN_OK;
 }
 
@@ -523,7 +532,7 @@ int ocean_compute_waves(ocean_t* c, float t, float* out_amp)
     HIP_TRY(hipSetDevice(c->device));
     int rc = enqueue_frame(c, t, true, nullptr);
     if (rc) return rc;
-    rc = fetch_minmax(c);
+    rc = fetch_minmax(c, true);        // waits for this frame's chain only
     if (rc) return rc;
     if (out_amp)
         for (uint32_t i = 0; i < c->tiles; ++i) out_amp[i] = amp_of(c, i, nullptr, nullptr);

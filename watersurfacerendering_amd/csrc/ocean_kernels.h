@@ -86,6 +86,7 @@ struct FrameArgs {
     float2* zh;              // [tiles][N/2+1][NUP]      row-transformed height, columns 0..N/2
     float* hraw;             // [tiles][NUP/8][N][8]     signed raw height, columns 0..N/2, 8-column tiles
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
+    unsigned* minmax_host;   // [tiles][2]       host-coherent copy, written by the displacement pass
     float4* disp;            // [tiles][N][N]
     float4* nrm;             // [tiles][N][N]
     const float* toff;       // [tiles] or null
@@ -710,8 +711,13 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
             for (int i = 0; i < LS::RL; ++i) hv[u][i] = hraw[hraw_index(N, j + i * LS::STRIDE, u0 + c)];
         }
     }
-    const float mn = key_float(a.minmax[2 * tile + 0]);
-    const float mx = key_float(a.minmax[2 * tile + 1]);
+    const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];
+    if (blockIdx.x == 0 && tid == 0) {      // final by now: hand the keys to the host (ocean_get_heights, ComputeWaves)
+        a.minmax_host[2 * tile + 0] = kmn;
+        a.minmax_host[2 * tile + 1] = kmx;
+    }
+    const float mn = key_float(kmn);
+    const float mx = key_float(kmx);
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
     const float lambda = a.lambda[tile];
     auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z0, nf, u0 + c, -1.0f); };
