@@ -152,6 +152,26 @@ def measure_sync_calls(W, n, device, calls=300):
             "what": "host-side wall time of ocean_compute_waves (enqueue + the frame + one stream synchronisation; min/max keys arrive in host-coherent memory), called from Python"}
 
 
+def measure_consumer(W, n, device, calls=200):
+    """Vertex-stage consumer: (n+1)^2 displaced vertices + normals from the maps of one frame."""
+    b = W.OceanBatch(n, 1, device)
+    b.prepare(SEED)
+    b.compute_waves(1.0)
+    L, h = W._abi.lib(), b._h
+    for _ in range(10):
+        L.ocean_displace_grid(h, 0, n, 1000.0 / 512.0, 1.0, -1.0)
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        L.ocean_displace_grid(h, 0, n, 1000.0 / 512.0, 1.0, -1.0)
+    b.synchronize()
+    per = (time.perf_counter() - t0) / calls
+    b.close()
+    verts = (n + 1) * (n + 1)
+    return {"size": n, "vertices": verts, "us_per_call": per * 1e6, "gvertices_per_s": verts / per * 1e-9,
+            "what": "ocean_displace_grid back to back on one stream: bilinear REPEAT sampling of both maps, positions + normals out"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -313,6 +333,8 @@ def main():
             extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 300, 20, mode=2)
             extra["512x512_synchronous_calls"] = measure_sync_calls(W, 512, local_rank)
             extra["2048x2048_synchronous_calls"] = measure_sync_calls(W, 2048, local_rank)
+            extra["vertex_stage_512"] = measure_consumer(W, 512, local_rank)
+            extra["vertex_stage_2048"] = measure_consumer(W, 2048, local_rank)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
             extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 100, 10, depth=2)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)

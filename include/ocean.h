@@ -156,15 +156,34 @@ int ocean_set_mode(ocean_t* ctx, int mode);
  * next ocean_prepare.  Accuracy: tests/test_parity_gpu.py states the measured bound.   */
 int ocean_set_spectrum_precision(ocean_t* ctx, int bits);
 
-/* Frame pipelining.  With depth 2 consecutive asynchronous frames alternate between
- * two independent chains (own stream, own intermediates, own internal map set): the
- * first pass of one frame fills the memory-idle phases of the other frame's map
- * passes.  ocean_synchronize and every synchronous call drain both; the read-out
- * functions and ocean_device_maps then refer to the frame enqueued last.  Caller-bound
+/* Frame pipelining.  With depth D consecutive asynchronous frames rotate over D
+ * independent chains (own stream, own intermediates, own internal map set): the
+ * first pass of one frame fills the memory-idle phases of the other frames' map
+ * passes.  ocean_compute_waves waits for its own frame only; ocean_synchronize and the
+ * read-out calls drain every chain; the read-out functions and ocean_device_maps then
+ * refer to the frame enqueued last.  Caller-bound
  * output buffers (ocean_bind_output) or a caller stream force depth 1.  depth 1 (the
  * default) = everything on one stream.  (The reference is strictly serial; its own
  * DOUBLE_BUFFERED switch, WaterSurfaceMesh.h:34, is the same idea on the upload side.)  */
-int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 or 2 */);
+int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 .. 8 */);
+
+/* ---- vertex-stage consumer ----------------------------------
+ * What the reference's vertex shader does with the two maps
+ * (src/shaders/WaterSurfaceMesh.vert:24-41) for the grid its mesh generator builds
+ * (WaterSurfaceMesh::CreateGridVertices, WaterSurfaceMesh.cpp:500-533), on the device:
+ * vertex (x, y), x, y = -grid_size/2 .. grid_size/2, sits at (x, 0, y) * vertex_distance with
+ * uv = (x + half, y + half) / grid_size; both maps are sampled at uv * uv_scale with the
+ * reference's sampler (LINEAR, REPEAT: vulkan/Sampler.cpp:60-66);
+ *   position = inPos + (D.x, D.y * A, D.z), w = D.w          (A = amplitude of the frame)
+ *   normal   = normalize(-s.x / (1 + choppy*s.z), 1, -s.y / (1 + choppy*s.w)), w = 0
+ * for the most recent frame of `tile`, ordered on its stream.  choppy is the value the
+ * reference feeds (GetDisplacementLambda(), WaterSurfaceMesh.cpp:172).  Results stay in
+ * device buffers owned by the context ((grid_size+1)^2 float4 each): ocean_read_grid copies
+ * them out (synchronises), ocean_device_grid hands out the pointers.                  */
+int ocean_displace_grid(ocean_t* ctx, uint32_t tile, uint32_t grid_size, float vertex_distance,
+                        float uv_scale, float choppy);
+int ocean_read_grid(ocean_t* ctx, float* positions, float* normals);
+int ocean_device_grid(ocean_t* ctx, void** d_positions, void** d_normals, uint32_t* vertices);
 
 /* The hipStream_t the most recent frame was enqueued on (as void*), and a way
  * to make the context use ONE caller-owned stream instead (this also disables

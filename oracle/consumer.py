@@ -1,0 +1,52 @@
+"""CPU restatement of the reference's vertex stage (TEST INFRASTRUCTURE ONLY: imported by tests/,
+never by the product path).
+
+Follows /root/reference/src/shaders/WaterSurfaceMesh.vert:24-41 for the grid of
+WaterSurfaceMesh::CreateGridVertices (/root/reference/src/scene/WaterSurfaceMesh.cpp:500-533), with the
+sampler the reference creates (vulkan/Sampler.cpp:60-66: LINEAR filter, REPEAT addressing).  Vulkan leaves
+the precision of the filter weights to the implementation; this restatement and the HIP kernel both use
+fp32 weights from frac(u*W - 0.5) and the evaluation order written below.  PARITY UNPINNED: the reference
+has no test or golden vector for this stage, and the shader cannot run here.
+"""
+import numpy as np
+
+F = np.float32
+
+
+def sample_linear_repeat(tex: np.ndarray, us: np.ndarray, vs: np.ndarray) -> np.ndarray:
+    """tex [N, N, 4] float32 (row = v, column = u); us, vs float32 arrays -> [..., 4] float32."""
+    n = tex.shape[0]
+    s = us * F(n) - F(0.5)
+    t = vs * F(n) - F(0.5)
+    fs, ft = np.floor(s), np.floor(t)
+    a, b = (s - fs)[..., None], (t - ft)[..., None]
+    x0 = fs.astype(np.int64) & (n - 1)
+    y0 = ft.astype(np.int64) & (n - 1)
+    x1, y1 = (x0 + 1) & (n - 1), (y0 + 1) & (n - 1)
+    t00, t10, t01, t11 = tex[y0, x0], tex[y0, x1], tex[y1, x0], tex[y1, x1]
+    ia, ib = F(1.0) - a, F(1.0) - b
+    return ((t00 * ia + t10 * a) * ib + (t01 * ia + t11 * a) * b).astype(np.float32)
+
+
+def displace_grid(disp: np.ndarray, nrm: np.ndarray, amp: float, grid: int, vertex_distance: float,
+                  uv_scale: float = 1.0, choppy: float = -1.0):
+    """Returns (positions, normals), each [(grid+1)^2, 4] float32, vertex i = y*(grid+1) + x."""
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    nrm = np.ascontiguousarray(nrm, dtype=np.float32)
+    side, half = grid + 1, grid // 2
+    i = np.arange(side * side)
+    xi, yi = i % side - half, i // side - half                       # WaterSurfaceMesh.cpp:514-518
+    px = xi.astype(np.float32) * F(vertex_distance)                  # .cpp:520-525
+    pz = yi.astype(np.float32) * F(vertex_distance)
+    u = (xi + half).astype(np.float32) / F(grid)                     # .cpp:528-531
+    v = (yi + half).astype(np.float32) / F(grid)
+    us, vs = u * F(uv_scale), v * F(uv_scale)                        # .vert:26
+    d = sample_linear_repeat(disp, us, vs)
+    dy = d[:, 1] * F(amp)                                            # .vert:27
+    pos = np.stack([px + d[:, 0], F(0.0) + dy, pz + d[:, 2], d[:, 3]], axis=1).astype(np.float32)   # .vert:28-29
+    sl = sample_linear_repeat(nrm, us, vs)                           # .vert:33
+    nx = -(sl[:, 0] / (F(1.0) + F(choppy) * sl[:, 2]))               # .vert:34-38
+    nz = -(sl[:, 1] / (F(1.0) + F(choppy) * sl[:, 3]))
+    ln = np.sqrt(nx * nx + F(1.0) + nz * nz)
+    out_n = np.stack([nx / ln, F(1.0) / ln, nz / ln, np.zeros_like(nx)], axis=1).astype(np.float32)
+    return pos, out_n

@@ -21,6 +21,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+from typing import Optional
+
 import numpy as np
 
 from . import _abi
@@ -136,6 +138,21 @@ class OceanBatch:
         d, q = C.c_void_p(), C.c_void_p()
         _abi.check(self._L.ocean_device_maps(self._h, C.byref(d), C.byref(q)), "ocean_device_maps")
         return d.value, q.value
+
+    def displace_grid(self, tile: int = 0, grid_size: Optional[int] = None, vertex_distance: Optional[float] = None,
+                      uv_scale: float = 1.0, choppy: float = -1.0):
+        """Vertex-stage consumer (WaterSurfaceMesh.vert:24-41 on the grid of WaterSurfaceMesh.cpp:500-533) of the
+        most recent frame: returns (positions, normals), each ((grid_size+1)^2, 4) float32.  Defaults are the
+        reference's: grid_size = tile size, vertex_distance = 1000/512 (WaterSurfaceMesh.h:199-202), choppy =
+        the default lambda."""
+        g = self.tile_size if grid_size is None else int(grid_size)
+        vd = (1000.0 / 512.0) if vertex_distance is None else float(vertex_distance)
+        _abi.check(self._L.ocean_displace_grid(self._h, tile, g, vd, uv_scale, choppy), "ocean_displace_grid")
+        pos = np.empty(((g + 1) * (g + 1), 4), dtype=np.float32)
+        nrm = np.empty_like(pos)
+        _abi.check(self._L.ocean_read_grid(self._h, pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
+                   "ocean_read_grid")
+        return pos, nrm
 
     def bind_output(self, d_disp: int | None, d_nrm: int | None):
         _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")

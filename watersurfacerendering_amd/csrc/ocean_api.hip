@@ -42,6 +42,7 @@ struct ocean_ctx {
     hipStream_t user = nullptr;
     int depth = 1;
     uint64_t frame_ctr = 0;
+    bool have_frame = false;        // a frame has been enqueued since the last ocean_prepare
     int last_set = 0;
 
     std::vector<ocean_params> params;
@@ -71,6 +72,9 @@ struct ocean_ctx {
     float* h0_inv_scale = nullptr;
     unsigned* h0_maxbits = nullptr;
     unsigned* h_minmax = nullptr;  // pinned
+    float4* grid_pos = nullptr;     // vertex-stage consumer output (ocean_displace_grid)
+    float4* grid_nrm = nullptr;
+    uint32_t grid_vertices = 0, grid_capacity = 0;
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t ev[8] = {};
     hipEvent_t end_ev[MAXD] = {};
@@ -229,6 +233,8 @@ void ocean_destroy(ocean_t* c)
     (void)sync_all(c);
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
+    if (c->grid_pos) (void)hipFree(c->grid_pos);
+    if (c->grid_nrm) (void)hipFree(c->grid_nrm);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
     for (auto& row : c->mark_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
@@ -347,6 +353,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     SYNC_ALL(c);
     c->seed = seed;
     c->prepared = true;
+    c->have_frame = false;
     return OCEAN_OK;
 }
 
@@ -487,6 +494,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     }
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
     if (pipe) c->frame_ctr++;
+    c->have_frame = true;
     c->last_set = set;
     return OCEAN_OK;
 }
@@ -620,6 +628,56 @@ int ocean_bind_output(ocean_t* c, void* d_disp, void* d_nrm)
     SYNC_ALL(c);
     c->ext_disp = (float4*)d_disp;
     c->ext_nrm = (float4*)d_nrm;
+    return OCEAN_OK;
+}
+
+int ocean_displace_grid(ocean_t* c, uint32_t tile, uint32_t grid_size, float vertex_distance, float uv_scale, float choppy)
+{
+    if (!c || tile >= c->tiles || grid_size == 0 || grid_size > 8192) return OCEAN_E_INVALID;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t verts = (grid_size + 1) * (grid_size + 1);
+    if (verts > c->grid_capacity) {
+        SYNC_ALL(c);
+        if (c->grid_pos) (void)hipFree(c->grid_pos);
+        if (c->grid_nrm) (void)hipFree(c->grid_nrm);
+        c->grid_pos = c->grid_nrm = nullptr; c->grid_capacity = 0;
+        HIP_TRY(hipMalloc(&c->grid_pos, (size_t)verts * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->grid_nrm, (size_t)verts * sizeof(float4)));
+        c->grid_capacity = verts;
+    }
+    const size_t n2 = (size_t)c->n * c->n;
+    GridArgs g;
+    g.disp = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + tile * n2;
+    g.nrm = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + tile * n2;
+    g.minmax = c->minmax[c->last_set] + 2 * tile;
+    g.positions = c->grid_pos; g.normals = c->grid_nrm;
+    g.n = (int)c->n; g.grid = (int)grid_size;
+    g.vertex_distance = vertex_distance; g.uv_scale = uv_scale; g.choppy = choppy;
+    // ordered after the frame that wrote these maps
+    hipLaunchKernelGGL(k_displace_grid, dim3((verts + 255) / 256), dim3(256), 0, stream_of(c, c->last_set), g);
+    HIP_TRY(hipGetLastError());
+    c->grid_vertices = verts;
+    return OCEAN_OK;
+}
+
+int ocean_read_grid(ocean_t* c, float* positions, float* normals)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (!c->grid_vertices) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    if (positions) HIP_TRY(hipMemcpy(positions, c->grid_pos, (size_t)c->grid_vertices * sizeof(float4), hipMemcpyDeviceToHost));
+    if (normals) HIP_TRY(hipMemcpy(normals, c->grid_nrm, (size_t)c->grid_vertices * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int ocean_device_grid(ocean_t* c, void** d_positions, void** d_normals, uint32_t* vertices)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (d_positions) *d_positions = c->grid_pos;
+    if (d_normals) *d_normals = c->grid_nrm;
+    if (vertices) *vertices = c->grid_vertices;
     return OCEAN_OK;
 }
 

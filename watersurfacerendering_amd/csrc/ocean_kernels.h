@@ -737,6 +737,69 @@ __global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs
     batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 }
 
+// ============================================================================
+// Vertex-stage consumer: what the reference's vertex shader does with
+// the two maps (src/shaders/WaterSurfaceMesh.vert:24-41) for the grid its mesh generator
+// builds (WaterSurfaceMesh.cpp:500-533), as a kernel -- displaced positions and normals for a
+// consumer that is not the Vulkan renderer.  Sampling is the sampler the reference creates
+// (vulkan/Sampler.cpp:60-66): LINEAR filter, REPEAT addressing, unnormalised coordinate
+// s = u*W - 0.5, texels floor(s) and floor(s)+1 (mod W), weights from frac(s), evaluated in
+// fp32 in the order written below (no contraction), which oracle/consumer.py repeats.
+// One thread per vertex; memory-bound (8 texel reads that mostly hit in cache, 2 writes).
+// ============================================================================
+struct GridArgs {
+    const float4* disp;      // [N][N] of the tile
+    const float4* nrm;
+    const unsigned* minmax;  // keys of the tile's raw height range (A = max(|min|, |max|) = WSHeightAmp)
+    float4* positions;       // [(g+1)^2]  xyz = displaced position, w = displacement.w (jacobian slot)
+    float4* normals;         // [(g+1)^2]  xyz = unit normal, w = 0
+    int n;                   // map size
+    int grid;                // quads per side (kTileSize of CreateGridVertices)
+    float vertex_distance;   // kScale
+    float uv_scale;          // ubo.scale
+    float choppy;            // ubo.WSChoppy = GetDisplacementLambda()
+};
+
+__device__ __forceinline__ float4 sample_linear_repeat(const float4* __restrict__ tex, int n, float u, float v)
+{
+#pragma clang fp contract(off)
+    const float s = u * (float)n - 0.5f, t = v * (float)n - 0.5f;
+    const float fs = floorf(s), ft = floorf(t);
+    const float a = s - fs, b = t - ft;
+    const int x0 = (int)fs & (n - 1), y0 = (int)ft & (n - 1);
+    const int x1 = (x0 + 1) & (n - 1), y1 = (y0 + 1) & (n - 1);
+    const float4 t00 = tex[(unsigned)(y0 * n + x0)], t10 = tex[(unsigned)(y0 * n + x1)];
+    const float4 t01 = tex[(unsigned)(y1 * n + x0)], t11 = tex[(unsigned)(y1 * n + x1)];
+    const float ia = 1.0f - a, ib = 1.0f - b;
+    auto mix = [&](float c00, float c10, float c01, float c11) {
+        return (c00 * ia + c10 * a) * ib + (c01 * ia + c11 * a) * b;
+    };
+    return make_float4(mix(t00.x, t10.x, t01.x, t11.x), mix(t00.y, t10.y, t01.y, t11.y),
+                       mix(t00.z, t10.z, t01.z, t11.z), mix(t00.w, t10.w, t01.w, t11.w));
+}
+
+__global__ void k_displace_grid(const GridArgs g)
+{
+#pragma clang fp contract(off)
+    const int side = g.grid + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= side * side) return;
+    const int half = g.grid / 2;
+    const int xi = i % side - half, yi = i / side - half;          // WaterSurfaceMesh.cpp:514-518
+    const float px = (float)xi * g.vertex_distance, pz = (float)yi * g.vertex_distance;
+    const float u = (float)(xi + half) / (float)g.grid, v = (float)(yi + half) / (float)g.grid;
+    const float amp = fmaxf(fabsf(key_float(g.minmax[0])), fabsf(key_float(g.minmax[1])));
+    const float us = u * g.uv_scale, vs = v * g.uv_scale;          // .vert:26
+    float4 d = sample_linear_repeat(g.disp, g.n, us, vs);
+    d.y = d.y * amp;                                               // .vert:27
+    g.positions[i] = make_float4(px + d.x, 0.0f + d.y, pz + d.z, d.w);   // .vert:28-29
+    const float4 sl = sample_linear_repeat(g.nrm, g.n, us, vs);    // .vert:33
+    const float nx = -(sl.x / (1.0f + g.choppy * sl.z));           // .vert:34-38
+    const float nz = -(sl.y / (1.0f + g.choppy * sl.w));
+    const float len = sqrtf(nx * nx + 1.0f + nz * nz);
+    g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
+}
+
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
 #define OCEAN_R(...) Radices<__VA_ARGS__>
