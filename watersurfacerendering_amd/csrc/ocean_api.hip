@@ -380,7 +380,7 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, bool stream_maps, hipStream_t st, hipEvent_t wait_before_cols,
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map */, hipStream_t st, hipEvent_t wait_before_cols,
                                hipEvent_t* marks /* 4 events or null */)
 {
     using G = Geo<N>;
@@ -431,13 +431,13 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, bool stream_map
     arm(1);
 #endif
     if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
-    if (stream_maps) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
+    if (stream_maps & 1) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
     else hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, false>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
     if (marks) (void)hipEventRecord(marks[2], st);
 #ifdef OCEAN_STAMPS
     arm(2);
 #endif
-    if (stream_maps) hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
+    if (stream_maps & 2) hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
     else hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
     if (marks) (void)hipEventRecord(marks[3], st);
     return hipGetLastError();
@@ -476,9 +476,9 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.t = t;
     a.mode = c->mode;
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
-    bool stream_maps = c->n >= 4096 || pipe;
-    static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs)
-    if (stream_env) stream_maps = atoi(stream_env) != 0;
+    int stream_maps = (c->n >= 4096 || pipe) ? 3 : 0;
+    static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs): bit mask
+    if (stream_env) stream_maps = atoi(stream_env);
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
         case 16: e = launch_frame<16>(c, a, stream_maps, st, wait, marks); break;
