@@ -224,16 +224,14 @@ template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() *
 template <int C>
 __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
 
-// Work-item -> (column c, butterfly j) of the LAST stage.  Default: c fastest (as in the
-// other stages).  For a batch whose items fill whole waves (and unless built with
-// -DOCEAN_LAST_CFASTEST), the
-// 64 lanes of a wave cover 64/C consecutive j of ONE column each, so a wave's store
-// instruction writes 64/C consecutive outputs per column contiguously (whole 128-byte
-// lines per 16-lane group) instead of C-interleaved 64-byte pieces.
+// Work-item -> (column c, butterfly j) of the LAST stage.  For a batch whose items fill whole
+// waves the 64 lanes of a wave cover 64/C consecutive j of ONE column each, so a wave's store
+// instruction writes 64/C consecutive outputs per column contiguously (whole 128-byte lines
+// per 16-lane group) instead of C-interleaved 64-byte pieces; otherwise c is fastest, as in
+// the other stages.
 template <int N, int C, int R>
 __device__ __forceinline__ void last_stage_map(int w, int& c, int& j)
 {
-#ifndef OCEAN_LAST_CFASTEST
     constexpr int ITEMS = (N / R) * C;
     if constexpr (ITEMS % 64 == 0 && 64 % C == 0 && C > 1) {
         constexpr int JB = 64 / C;
@@ -241,7 +239,6 @@ __device__ __forceinline__ void last_stage_map(int w, int& c, int& j)
         j = (w % JB) + JB * (w / 64);
         return;
     }
-#endif
     c = w % C;
     j = w / C;
 }

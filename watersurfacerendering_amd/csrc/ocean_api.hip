@@ -76,8 +76,8 @@ struct ocean_ctx {
     float4* grid_nrm = nullptr;
     uint32_t grid_vertices = 0, grid_capacity = 0;
     unsigned long long* stamps = nullptr;   // diagnostic builds only
-    hipEvent_t ev[8] = {};
-    hipEvent_t end_ev[MAXD] = {};
+    hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
+    hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
     hipEvent_t mark_ev[MAXD][4] = {};   // per-launch timing in pipelined mode
 };
 
@@ -215,7 +215,7 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
             if (hipStreamCreateWithFlags(&c->own[i], hipStreamNonBlocking) != hipSuccess) rc = OCEAN_E_HIP;
         if (rc) break;
         if (hipHostMalloc((void**)&c->h_minmax, tiles * 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = OCEAN_E_HIP; break; }
-        for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
+        if (hipEventCreate(&c->start_ev) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& e : c->end_ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& row : c->mark_ev) for (auto& e : row) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         if (rc) break;
@@ -235,7 +235,7 @@ void ocean_destroy(ocean_t* c)
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->grid_pos) (void)hipFree(c->grid_pos);
     if (c->grid_nrm) (void)hipFree(c->grid_nrm);
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
     for (auto& row : c->mark_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < MAXD; ++i)
@@ -380,8 +380,8 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map */, hipStream_t st, hipEvent_t wait_before_cols,
-                               hipEvent_t* marks /* 4 events or null */)
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map */,
+                               hipStream_t st, hipEvent_t* marks /* 4 events or null */)
 {
     using G = Geo<N>;
     using HF = Half<N>;
@@ -430,7 +430,6 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
     arm(1);
 #endif
-    if (wait_before_cols && (e = hipStreamWaitEvent(st, wait_before_cols, 0)) != hipSuccess) return e;
     if (stream_maps & 1) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
     else hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, false>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
     if (marks) (void)hipEventRecord(marks[2], st);
@@ -443,7 +442,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     return hipGetLastError();
 }
 
-// Enqueues one frame.  pipelined = use the two-set / two-stream scheme.
+// Enqueues one frame.  pipelined = the call may use the pipeline chains (depth > 1).
 static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks)
 {
     if (!c) return OCEAN_E_INVALID;
@@ -463,7 +462,6 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         if (rc_) return rc_;
     }
     hipStream_t st = stream_of(c, set);
-    hipEvent_t wait = nullptr;
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
@@ -481,15 +479,15 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     if (stream_env) stream_maps = atoi(stream_env);
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
-        case 16: e = launch_frame<16>(c, a, stream_maps, st, wait, marks); break;
-        case 32: e = launch_frame<32>(c, a, stream_maps, st, wait, marks); break;
-        case 64: e = launch_frame<64>(c, a, stream_maps, st, wait, marks); break;
-        case 128: e = launch_frame<128>(c, a, stream_maps, st, wait, marks); break;
-        case 256: e = launch_frame<256>(c, a, stream_maps, st, wait, marks); break;
-        case 512: e = launch_frame<512>(c, a, stream_maps, st, wait, marks); break;
-        case 1024: e = launch_frame<1024>(c, a, stream_maps, st, wait, marks); break;
-        case 2048: e = launch_frame<2048>(c, a, stream_maps, st, wait, marks); break;
-        case 4096: e = launch_frame<4096>(c, a, stream_maps, st, wait, marks); break;
+        case 16: e = launch_frame<16>(c, a, stream_maps, st, marks); break;
+        case 32: e = launch_frame<32>(c, a, stream_maps, st, marks); break;
+        case 64: e = launch_frame<64>(c, a, stream_maps, st, marks); break;
+        case 128: e = launch_frame<128>(c, a, stream_maps, st, marks); break;
+        case 256: e = launch_frame<256>(c, a, stream_maps, st, marks); break;
+        case 512: e = launch_frame<512>(c, a, stream_maps, st, marks); break;
+        case 1024: e = launch_frame<1024>(c, a, stream_maps, st, marks); break;
+        case 2048: e = launch_frame<2048>(c, a, stream_maps, st, marks); break;
+        case 4096: e = launch_frame<4096>(c, a, stream_maps, st, marks); break;
         default: return OCEAN_E_UNSUPPORTED;
     }
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
@@ -762,8 +760,8 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     for (int j = 0; j < warmup; ++j)
         if ((rc = enqueue_frame(c, t0 + dt * (float)j, true, nullptr))) return rc;
     SYNC_ALL(c);
-    HIP_TRY(hipEventRecord(c->ev[4], stream_of(c, 0)));
-    HIP_TRY(hipEventSynchronize(c->ev[4]));
+    HIP_TRY(hipEventRecord(c->start_ev, stream_of(c, 0)));
+    HIP_TRY(hipEventSynchronize(c->start_ev));
     for (int j = 0; j < frames; ++j)
         if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), true, nullptr))) return rc;
     // the two chains are independent: the timed region ends when the later one does
@@ -773,7 +771,7 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     float ms = 0.f;
     for (int i = 0; i < nstreams; ++i) {
         float m = 0.f;
-        HIP_TRY(hipEventElapsedTime(&m, c->ev[4], c->end_ev[i]));
+        HIP_TRY(hipEventElapsedTime(&m, c->start_ev, c->end_ev[i]));
         if (m > ms) ms = m;
     }
     if (ms_total) *ms_total = ms;

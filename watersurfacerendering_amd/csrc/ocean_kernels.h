@@ -35,6 +35,11 @@
 #include <stdint.h>
 #include "fft_engine.h"
 
+// Diagnostic builds (never shipped; `make -C csrc variant NAME=x DEFS=...`): -DOCEAN_STAMPS records
+// per-workgroup phase clocks (tools/stamps.py); -DOCEAN_ABL_NOLOAD / _NOSTORE / _NOMAPSTORE / _NOFFT /
+// _NOIN / _SINCOS remove the global loads, the intermediate stores, the map stores, the butterfly
+// arithmetic, the z-pass input arithmetic or the sincos -- results are then wrong on purpose; they
+// only attribute time.
 namespace ocean {
 
 typedef float ocean_f4 __attribute__((ext_vector_type(4)));
@@ -399,13 +404,10 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // Two batches of two interleaved transforms over e: {pair 0, pair 1}, {pair 2, height};
 // output index p = z position; stored per column nb as side 0 (p <= N/2) / side 1 (N-p).
 // ============================================================================
-#ifndef OCEAN_ZPASS_MINW
-#define OCEAN_ZPASS_MINW 1
-#endif
 // minimum waves per SIMD asked of the register allocator: 2048 fits 80 VGPRs without a
 // spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
 // 1024 and 4096 would spill at that cap and keep the looser one
-template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : OCEAN_ZPASS_MINW); }
+template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
 template <int N, int T, class P = Plan<N>, bool H16 = false>
 __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
@@ -434,10 +436,7 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     {
         constexpr int ELEMS = N;                      // 2 columns * N/2 element pairs
         constexpr int P1 = (ELEMS + T - 1) / T;
-#ifndef OCEAN_PB
-#define OCEAN_PB 4
-#endif
-        constexpr int PB = P1 > OCEAN_PB ? OCEAN_PB : P1;
+        constexpr int PB = P1 > 4 ? 4 : P1;          // loads in flight per thread (8 was measured no better)
         static_assert(P1 % PB == 0, "phase-1 batches");
 #pragma unroll 1
         for (int ub = 0; ub < P1; ub += PB) {
@@ -554,11 +553,8 @@ __device__ __forceinline__ void for_each_output(int tid, F f)
 // one height launch, then all three pairs per workgroup with register prefetch -- was
 // measured slower at every size and removed.)
 // ============================================================================
-#ifndef OCEAN_XB_MINW
-#define OCEAN_XB_MINW 1
-#endif
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
-__global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
+__global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
@@ -681,11 +677,8 @@ __global__ void __launch_bounds__(T, OCEAN_XB_MINW) k_xpass_b(const FrameArgs a)
     }
 }
 
-#ifndef OCEAN_XD_MINW
-#define OCEAN_XD_MINW 1
-#endif
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
-__global__ void __launch_bounds__(T, OCEAN_XD_MINW) k_xpass_disp(const FrameArgs a)
+__global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
