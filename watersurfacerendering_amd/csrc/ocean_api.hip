@@ -34,10 +34,10 @@ struct ocean_ctx {
     uint32_t tiles = 0;
     int device = 0;
     bool prepared = false;
-    // Frames alternate between two intermediate-buffer sets, each with its own
-    // stream, so the row pass of frame f+1 overlaps the column passes of frame f
-    // (pipeline depth 2).  Map writes stay in frame order (event chain).  A
-    // caller-supplied stream, or depth 1, runs everything on one stream / set 0.
+    // At pipeline depth D asynchronous frames rotate over D chains, each with its own
+    // stream, intermediates and internal map set and no dependency on the others, so the
+    // z pass of one frame overlaps the map passes of the others.  A caller-supplied
+    // stream, caller-bound output or depth 1 runs everything on one stream / set 0.
     hipStream_t own[MAXD] = {};
     hipStream_t user = nullptr;
     int depth = 1;

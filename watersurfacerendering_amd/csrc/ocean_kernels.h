@@ -10,20 +10,21 @@
 //      and two real-output fields share one complex transform.
 //  (2) every X_f is even or odd under index inversion (m,n) -> (-m,-n) mod N,
 //      hence so is every output field: out(-p,-q) = eps_f * out(p,q)
-//      (height, dDx/dx, dDz/dz even; Dx, Dz, slopes odd).  Only rows 0..N/2 of
-//      the row pass and columns 0..N/2 of the column pass are transformed; the
-//      other half is the mirror image.  (Checked bit-exactly against the
-//      oracle: tests/test_oracle.py::test_reference_output_point_symmetry.)
+//      (height, dDx/dx, dDz/dz even; Dx, Dz, slopes odd).  Only spectrum columns 0..N/2
+//      go through the first (z-axis) pass and only map rows 0..N/2 through the second
+//      (x-axis) pass; the other half is the mirror image.  (Checked bit-exactly against
+//      the oracle: tests/test_oracle.py::test_reference_output_point_symmetry.)
 //
-//   k_rows      one spectrum row m in [0, N/2] per workgroup: animate rows m and
-//               -m, S+ = (a+b)/2, S- = (a-b)/2, build the three packed pairs and
-//               the height from S+/S- and the wave-vector coefficients, four
-//               row (x-axis) inverse FFTs.
-//   k_xpass_b    column (z-axis) pass, part 1, one launch, two kinds of
-//               workgroup: HEIGHT (two real columns per complex transform,
-//               sign, raw heights out, global min/max by atomics) and NORMAL
-//               (pairs 1 and 2 -> finished normal map, both mirror halves).
-//   k_xpass_disp part 2, needs the min/max: pair 0 + raw height -> displacement map.
+//   k_zpass      one spectrum column nb (kx index) in [0, N/2] per workgroup: animate
+//                columns nb and -nb (contiguous runs of the transposed spectrum),
+//                S+ = (a+b)/2, S- = (a-b)/2, build the three packed pairs and the height
+//                from S+/S- and the wave-vector coefficients, four z-axis inverse FFTs.
+//   k_xpass_b    x-axis pass, part 1, one launch, two kinds of workgroup: HEIGHT (two
+//                real rows per complex transform, sign, raw heights out, global
+//                min/max by atomics) and NORMAL (pairs 1 and 2 -> finished normal-map
+//                rows q and N-q).
+//   k_xpass_disp part 2, needs the min/max: pair 0 + raw height -> displacement-map rows.
+//   The x axis goes last so that every map row is written as whole contiguous lines.
 //
 // HBM bytes per texel actually moved (this pipeline): 12 (h0, omega) + 14 + 14
 // (half-size intermediates out and in) + 2 + 2 (raw height) + 32 (maps) = 76,
@@ -507,7 +508,7 @@ template <int N> constexpr size_t zpass_lds_bytes()
     return sizeof(c32) * fft_lds_elems<N, 2>() + sizeof(float) * 2 * N;
 }
 
-// ---- column pass helpers -----------------------------------------------------------
+// ---- x-pass helpers ------------------------------------------------------------------
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the
 // mirror image eps * Z(N-mf, N-u) = eps * side 1 of row N-mf.
 template <int N>
