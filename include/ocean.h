@@ -70,7 +70,7 @@ int         ocean_last_hip_error(void);
 
 /* ---- lifetime: replaces WSTessendorf::WSTessendorf / ~WSTessendorf
  *      (WSTessendorf.cpp:13-34).  tile_size must be a power of two in
- *      [16, 4096] (.cpp:459-468 rejects non powers of two); tiles >= 1.
+ *      [16, 4096] (.cpp:459-468 rejects non powers of two); 1 <= tiles <= 65535.
  *      device = HIP device ordinal.                                              */
 int  ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device);
 void ocean_destroy(ocean_t* ctx);

@@ -195,6 +195,7 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
 {
     if (!out || tiles == 0) return OCEAN_E_INVALID;
     *out = nullptr;
+    if (tiles > 65535) return OCEAN_E_UNSUPPORTED;        // tiles are blockIdx.y of every launch
     if (tile_size == 0 || (tile_size & (tile_size - 1))) return OCEAN_E_INVALID;
     if (!size_ok(tile_size)) return OCEAN_E_UNSUPPORTED;
     int count = 0;
