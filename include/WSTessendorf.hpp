@@ -77,7 +77,7 @@ public:
         m_Params.tile_length = tileLength;
         Push();
     }
-    ~WSTessendorf() { ocean_destroy(m_Ctx); }
+    ~WSTessendorf() { Unpin(); ocean_destroy(m_Ctx); }
     WSTessendorf(const WSTessendorf&) = delete;
     WSTessendorf& operator=(const WSTessendorf&) = delete;
 
@@ -91,8 +91,16 @@ public:
     {
         Check(ocean_prepare(m_Ctx, seed, gaussRandomOrNull), "ocean_prepare");
         const size_t n = ocean_tile_size(m_Ctx);
+        Unpin();
         m_Displacements.assign(n * n, Displacement(0.f, 0.f, 0.f, 0.f));     // .cpp:48-51
         m_Normals.assign(n * n, Normal(0.f, 1.f, 0.f, 0.f));                 // .cpp:53-54
+        // page-lock the two host vectors so the per-frame read-out is a direct DMA (best effort:
+        // a pageable vector still works, the copy is then staged by the runtime)
+        m_Pinned = ocean_host_register(m_Displacements.data(), n * n * sizeof(Displacement)) == OCEAN_OK;
+        if (m_Pinned && ocean_host_register(m_Normals.data(), n * n * sizeof(Normal)) != OCEAN_OK) {
+            ocean_host_unregister(m_Displacements.data());
+            m_Pinned = false;
+        }
     }
 
     // WSTessendorf.cpp:284-455: returns the amplitude of the normalised heights
@@ -150,6 +158,13 @@ public:
     ocean_t* Context() const { return m_Ctx; }
 
 private:
+    void Unpin()
+    {
+        if (!m_Pinned) return;
+        ocean_host_unregister(m_Displacements.data());
+        ocean_host_unregister(m_Normals.data());
+        m_Pinned = false;
+    }
     void Push() { Check(ocean_set_params(m_Ctx, OCEAN_ALL_TILES, &m_Params), "ocean_set_params"); }
     static void Check(int rc, const char* what)
     {
@@ -165,6 +180,7 @@ private:
     float m_MinHeight{ -1.0f };     // WSTessendorf.h:227-228
     float m_MaxHeight{ 1.0f };
     uint64_t m_PrepareCount{ 0 };
+    bool m_Pinned{ false };
 };
 
 #endif  // WS_TESSENDORF_ADAPTOR_HPP_

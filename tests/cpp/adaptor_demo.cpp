@@ -3,6 +3,7 @@
 // frame, then both maps memcpy'd back to back into one staging buffer.
 // Prints "N A min max sum_disp sum_nrm" so the GPU test can compare it with the
 // Python binding on the same seed.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,17 @@ int main(int argc, char** argv)
         for (size_t i = dispBytes / 4; i < (dispBytes + nrmBytes) / 4; ++i) sn += (double)f[i] * (double)((i % 5) + 1);
         std::printf("%u %.9g %.9g %.9g %.12g %.12g\n", model.GetTileSize(), amp, model.GetMinHeight(),
                     model.GetMaxHeight(), sd, sn);
+        // optional third argument: time that many frames the way WaterSurfaceMesh::Update does
+        // (ComputeWaves + both maps in host memory), reported on stderr
+        const int frames = argc > 3 ? std::atoi(argv[3]) : 0;
+        if (frames > 0) {
+            for (int j = 0; j < 5; ++j) model.ComputeWaves(t + 0.05f * (float)j);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int j = 0; j < frames; ++j) model.ComputeWaves(t + 0.05f * (float)j);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "adaptor_demo: N=%u ComputeWaves + read-out of both maps: %.1f us/frame\n",
+                         model.GetTileSize(), us / frames);
+        }
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "adaptor_demo: %s\n", e.what());
