@@ -69,6 +69,18 @@ template <bool NTS> __device__ __forceinline__ void store_map(float4* base, unsi
 }
 #define OCEAN_STORE(base, texel, val) store_map<NTS>((base), (unsigned)(texel), (val))
 
+// Element `idx` of a per-tile array through a 32-bit BYTE offset (every per-tile array here is far
+// below 4 GiB): the access then addresses as scalar base + 32-bit vector offset instead of a 64-bit
+// vector address per access -- one VGPR instead of two per outstanding load and no 64-bit adds.
+template <class T> __device__ __forceinline__ const T& at32(const T* base, unsigned idx)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
+}
+template <class T> __device__ __forceinline__ T& at32(T* base, unsigned idx)
+{
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(T));
+}
+
 struct TileParams {          // device copy of one tile's properties
     float wind_x, wind_y;    // unit vector (SetWindDirection, .cpp:476-479)
     float wind_speed;        // (.cpp:481-484)
@@ -355,7 +367,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #endif
             // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored
             // positions 0 and N/2 exist on side 0 only: the x pass knows)
-            zt[(unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))] = v;
+            at32(zt, (unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))) = v;
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -381,10 +393,10 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (p <= N / 2) zh[(unsigned)p] = v;                // real input: other half is the conjugate
+                if (p <= N / 2) at32(zh, (unsigned)p) = v;          // real input: other half is the conjugate
                 return;
             }
-            zt[(unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))] = v;
+            at32(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))) = v;
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -518,10 +530,10 @@ __device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, i
 #ifdef OCEAN_ABL_NOLOAD
     return make_float2(1.0f + mf, 0.5f * u);
 #endif
-    if (mf <= N / 2) return zg[(unsigned)(mf * 2 * HF::NUP + u)];
+    if (mf <= N / 2) return at32(zg, (unsigned)(mf * 2 * HF::NUP + u));
     // mirror of the self-mirrored units 0 and N/2 is the unit itself (side 0)
     const int side = (u == 0 || u == N / 2) ? 0 : 1;
-    const c32 v = zg[(unsigned)(((N - mf) * 2 + side) * HF::NUP + u)];
+    const c32 v = at32(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u));
     return make_float2(eps * v.x, eps * v.y);
 }
 
@@ -577,7 +589,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
         auto in = [&](int nf, int c, int, int) -> c32 {
             const int row = nf <= N / 2 ? nf : N - nf;
-            const float4 z = *reinterpret_cast<const float4*>(zh + (unsigned)(row * HF::NUP + u0 + 2 * c));
+            const float4 z = *reinterpret_cast<const float4*>(&at32(zh, (unsigned)(row * HF::NUP + u0 + 2 * c)));
             if (nf == 0 || nf == N / 2) return make_float2(z.x, z.z);
             if (nf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
             return make_float2(z.x + z.w, z.z - z.y);
@@ -588,7 +600,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             const float ha = s * v.x, hb = -s * v.y;
             if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
             if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
-            *reinterpret_cast<float2*>(hraw + hraw_index(N, p, u)) = make_float2(ha, hb);
+            *reinterpret_cast<float2*>(&at32(hraw, hraw_index(N, p, u))) = make_float2(ha, hb);
         };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 #pragma unroll
@@ -702,7 +714,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
             int c, j;
             LS::map(w, c, j);
 #pragma unroll
-            for (int i = 0; i < LS::RL; ++i) hv[u][i] = hraw[hraw_index(N, j + i * LS::STRIDE, u0 + c)];
+            for (int i = 0; i < LS::RL; ++i) hv[u][i] = at32(hraw, hraw_index(N, j + i * LS::STRIDE, u0 + c));
         }
     }
     const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];
