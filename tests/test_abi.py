@@ -132,6 +132,22 @@ def test_cpp_adaptor_has_reference_surface_and_links(abi, tmp_path):
         assert r.returncode == 3 and "no usable HIP device" in r.stderr   # loud failure, no fallback
 
 
+def test_abi_header_is_plain_c99(abi, tmp_path):
+    """The boundary is a C ABI: include/ocean.h must compile as strict C99 and link from a C program."""
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "ocean.h"\n#include <stdio.h>\n'
+                   'int main(void) { ocean_params p; ocean_t* h = 0; ocean_default_params(&p);\n'
+                   '  if (ocean_abi_version() <= 0 || p.tile_length != 1000.0f) return 1;\n'
+                   '  if (ocean_create(&h, 500, 1, 0) != OCEAN_E_INVALID) return 2;   /* not a power of two */\n'
+                   '  printf("%s\\n", ocean_strerror(OCEAN_E_NO_DEVICE)); return 0; }\n')
+    exe = tmp_path / "c_abi"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", os.path.dirname(abi.LIB_PATH), "-locean_hip", "-Wl,-rpath," + os.path.dirname(abi.LIB_PATH),
+                    "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip()
+
+
 def test_missing_extension_fails_loudly():
     """No silent fallback: without the built .so the package refuses to work."""
     code = ("import watersurfacerendering_amd as W\n"
