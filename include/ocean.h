@@ -150,6 +150,15 @@ int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
 enum { OCEAN_MODE_FULL7 = 0, OCEAN_MODE_CHOPPY5 = 1, OCEAN_MODE_HEIGHT1 = 2 };
 int ocean_set_mode(ocean_t* ctx, int mode);
 
+/* Dispersion relation of the next ocean_prepare (all tiles).  OCEAN_DISPERSION_DEEP (default) is the
+ * one the reference uses, sqrt(g k) (WSTessendorf.h:290-293 via QDispersion :284-287).  The other two are
+ * the relations the reference defines but never calls: finite depth
+ * sqrt(g k tanh(k D)) with param = D in metres (DispersionTransWaves, .h:301-304) and small waves
+ * sqrt(g k (1 + k^2 L^2)) with param = L (DispersionSmallWaves, .h:312-315).  The quantisation of
+ * .h:284-287 (floor(w / w0) * w0) is applied to all three so the animation stays periodic.   */
+enum { OCEAN_DISPERSION_DEEP = 0, OCEAN_DISPERSION_FINITE_DEPTH = 1, OCEAN_DISPERSION_CAPILLARY = 2 };
+int ocean_set_dispersion(ocean_t* ctx, int kind, float param);
+
 /* Spectrum storage precision: 32 (default) or 16.  With 16 the per-frame passes read a
  * half2 copy of h0(k), scaled per tile by a power of two, instead of the fp32 one
  * (8 instead of 12 bytes per texel of input; omega stays fp32).  Takes effect at the

@@ -61,6 +61,8 @@ typedef struct oracle_ctx {
     float anim_period;
     float base_freq;
     float lambda;
+    int dispersion;          /* 0 deep water (the only one the reference calls), 1 finite depth, 2 capillary */
+    float dispersion_param;  /* depth D, or wavelength L */
     float min_height, max_height;
     int prepared;
     /* Prepare() products: WSTessendorf.h:211-215 */
@@ -112,6 +114,25 @@ void oracle_set_animation_period(oracle_ctx* c, float t)
 void oracle_set_phillips_const(oracle_ctx* c, float a) { c->phillips_a = a; c->prepared = 0; } /* :492-495 */
 void oracle_set_lambda(oracle_ctx* c, float l) { c->lambda = l; }                             /* :497-500 */
 void oracle_set_damping(oracle_ctx* c, float d) { c->damping = d; c->prepared = 0; }         /* :502-505 */
+
+/* The two dispersion relations WSTessendorf.h defines but never calls:
+ * kind 1 = DispersionTransWaves(k, D) (.h:301-304), kind 2 = DispersionSmallWaves(k, L) (.h:312-315);
+ * kind 0 = DispersionDeepWaves (.h:290-293, what QDispersion uses).  The quantisation of .h:284-287 is
+ * applied to all of them so that the animation stays periodic. */
+void oracle_set_dispersion(oracle_ctx* c, int kind, float param)
+{
+    c->dispersion = kind; c->dispersion_param = param; c->prepared = 0;
+}
+static float dispersion_of(const oracle_ctx* c, float k)
+{
+    if (c->dispersion == 1)      /* sqrt(g k tanh(k D)): tanhf is libm-dependent, so evaluated in double, rounded once */
+        return (float)sqrt((double)(9.81f * k) * tanh((double)k * (double)c->dispersion_param));
+    if (c->dispersion == 2) {    /* sqrt(g k (1 + k^2 L^2)), float, left to right like the reference expression */
+        const float l = c->dispersion_param;
+        return sqrtf(9.81f * k * (1.0f + k * k * l * l));
+    }
+    return sqrtf(9.81f * k);
+}
 
 uint32_t oracle_tile_size(const oracle_ctx* c) { return c->n; }
 float oracle_min_height(const oracle_ctx* c) { return c->min_height; }
@@ -265,7 +286,7 @@ int oracle_prepare(oracle_ctx* c, uint64_t seed, const float* xi_or_null)
             c->h0[2 * i + 1] = (inv_sqrt2 * gi) * sp;
             c->h0c[2 * i] = (inv_sqrt2 * gr) * sm;
             c->h0c[2 * i + 1] = -((inv_sqrt2 * gi) * sm);
-            c->omega[i] = floorf(sqrtf(9.81f * k) / c->base_freq) * c->base_freq;
+            c->omega[i] = floorf(dispersion_of(c, k) / c->base_freq) * c->base_freq;
         } else {
             c->h0[2 * i] = c->h0[2 * i + 1] = 0.0f;
             c->h0c[2 * i] = 0.0f; c->h0c[2 * i + 1] = -0.0f;

@@ -53,6 +53,8 @@ def lib() -> C.CDLL:
             getattr(L, "oracle_set_" + name).restype = None
         L.oracle_set_wind_direction.argtypes = [P, C.c_float, C.c_float]
         L.oracle_set_wind_direction.restype = None
+        L.oracle_set_dispersion.argtypes = [P, C.c_int, C.c_float]
+        L.oracle_set_dispersion.restype = None
         L.oracle_prepare.argtypes = [P, C.c_uint64, C.c_void_p]
         L.oracle_prepare.restype = C.c_int
         L.oracle_compute_waves.argtypes = [P, C.c_float, C.c_int, C.c_int]
@@ -75,7 +77,8 @@ def lib() -> C.CDLL:
 
 
 DEFAULTS = dict(length=1000.0, wind=(1.0, 1.0), wind_speed=30.0, anim_period=200.0,
-                phillips_a=3e-7, damping=0.1, lam=-1.0)
+                phillips_a=3e-7, damping=0.1, lam=-1.0, dispersion=(0, 0.0))
+DISPERSION_DEEP, DISPERSION_FINITE_DEPTH, DISPERSION_CAPILLARY = 0, 1, 2    # WSTessendorf.h:290-293, 301-304, 312-315
 
 
 class Oracle:
@@ -95,6 +98,7 @@ class Oracle:
         self._L.oracle_set_phillips_const(self._h, p["phillips_a"])
         self._L.oracle_set_damping(self._h, p["damping"])
         self._L.oracle_set_lambda(self._h, p["lam"])
+        self._L.oracle_set_dispersion(self._h, int(p["dispersion"][0]), float(p["dispersion"][1]))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -181,7 +185,7 @@ def gauss_xi_numpy(seed: int, n: int) -> np.ndarray:
 # tests/test_oracle.py requires the two to agree.
 
 def numpy_prepare(n, xi, length=1000.0, wind=(1.0, 1.0), wind_speed=30.0, anim_period=200.0,
-                  phillips_a=3e-7, damping=0.1, **_):
+                  phillips_a=3e-7, damping=0.1, dispersion=(0, 0.0), **_):
     f32 = np.float32
     wx, wy = f32(wind[0]), f32(wind[1])
     inv = f32(1.0) / np.sqrt(wx * wx + wy * wy, dtype=f32)
@@ -214,8 +218,15 @@ def numpy_prepare(n, xi, length=1000.0, wind=(1.0, 1.0), wind_speed=30.0, anim_p
         sp = np.sqrt(ph, dtype=f32)
         h0r = np.where(ok, ((s * xi[..., 0]).astype(f32) * sp).astype(f32), f32(0))   # .h:237-243
         h0i = np.where(ok, ((s * xi[..., 1]).astype(f32) * sp).astype(f32), f32(0))
-        om = np.where(ok, (np.floor((np.sqrt((f32(9.81) * klen).astype(f32), dtype=f32) / base).astype(f32))
-                           * base).astype(f32), f32(0))                     # .h:284-297
+        gk = (f32(9.81) * klen).astype(f32)
+        if dispersion[0] == 1:      # .h:301-304, evaluated in double and rounded once (tanhf is libm-dependent)
+            w = np.sqrt(gk.astype(np.float64) * np.tanh(klen.astype(np.float64) * np.float64(f32(dispersion[1])))).astype(f32)
+        elif dispersion[0] == 2:    # .h:312-315, float, left to right
+            ll = f32(dispersion[1])
+            w = np.sqrt((gk * (f32(1.0) + (((klen * klen).astype(f32) * ll).astype(f32) * ll).astype(f32)).astype(f32)).astype(f32), dtype=f32)
+        else:                       # .h:290-293
+            w = np.sqrt(gk, dtype=f32)
+        om = np.where(ok, (np.floor((w / base).astype(f32)) * base).astype(f32), f32(0))      # .h:284-287
     return dict(kx=kx, kz=kz, ux=ux, uz=uz, h0=(h0r + 1j * h0i).astype(np.complex64), omega=om.astype(f32))
 
 

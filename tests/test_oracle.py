@@ -169,6 +169,22 @@ def test_spatial_mean_is_zero():
         assert abs(a.mean()) <= 1e-6 * np.abs(a).max()
 
 
+@pytest.mark.parametrize("dispersion", [(1, 2.0), (2, 5.0)])
+def test_other_dispersion_relations_c_vs_numpy(dispersion):
+    """WSTessendorf.h:301-315 (defined, never called by the reference): C oracle against the numpy restatement."""
+    from oracle import oracle as O
+    n = 64
+    xi = O.gauss_xi_numpy(11, n)
+    o = O.Oracle(n, dispersion=dispersion)
+    o.prepare(xi=xi)
+    p = O.numpy_prepare(n, xi.reshape(n, n, 2), dispersion=dispersion)
+    assert np.array_equal(o.omega.reshape(n, n), p["omega"])
+    d = O.Oracle(n)
+    d.prepare(xi=xi)
+    assert not np.array_equal(d.omega, o.omega)
+    assert np.array_equal(d.h0, o.h0)                       # only the dispersion changes
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ocean_n*.npz"))))
 def test_golden_fixtures(path):
     g = np.load(path)

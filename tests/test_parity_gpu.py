@@ -33,9 +33,11 @@ def make_oracle(n, xi, length=1000.0, **kw):
 
 
 def make_gpu(n, xi, seed=0, length=1000.0, wind=(1.0, 1.0), wind_speed=30.0, anim_period=200.0,
-             phillips_a=3e-7, damping=0.1, lam=-1.0, tiles=1):
+             phillips_a=3e-7, damping=0.1, lam=-1.0, tiles=1, dispersion=None):
     import watersurfacerendering_amd as W
     b = W.OceanBatch(n, tiles, 0)
+    if dispersion is not None:
+        b.set_dispersion(*dispersion)
     b.set_params(tile_length=length, wind_dir_x=wind[0], wind_dir_y=wind[1], wind_speed=wind_speed,
                  anim_period=anim_period, phillips_const=phillips_a, damping=damping, lambda_=lam)
     b.prepare(seed, xi)
@@ -78,6 +80,32 @@ def test_negative_and_very_large_times(n):
     b = make_gpu(n, xi[None])
     for t in (-3.25, 9.0e3, 5.0e4, 3.0e5, 2.5e6):
         check_frame(b, o, t)
+    b.close()
+
+
+@pytest.mark.parametrize("dispersion", [(1, 2.0), (1, 40.0), (2, 5.0)])
+@pytest.mark.parametrize("n", [64, 256])
+def test_other_dispersion_relations(n, dispersion):
+    """the finite-depth and small-wave relations the reference defines (WSTessendorf.h:301-315)
+    but never calls.  Device omega against the oracle's (the finite-depth one goes through a double tanh on both
+    sides: at most a couple of quantisation steps may differ), then the maps."""
+    from oracle import oracle as O
+    xi = O.gauss_xi_numpy(2468, n)
+    o = make_oracle(n, xi, dispersion=dispersion)
+    b = make_gpu(n, xi[None], dispersion=dispersion)
+    _, om = b.read_spectrum(0)
+    differing = int((om != o.omega).sum())
+    assert differing <= (2 if dispersion[0] == 1 else 0), differing
+    deep = make_oracle(n, xi)
+    assert not np.array_equal(deep.omega, o.omega)                  # the option has an effect at these parameters
+    if differing == 0:
+        for t in (0.0, 2.5, 400.0):
+            check_frame(b, o, t)
+    import watersurfacerendering_amd as W
+    with pytest.raises(W.OceanError):
+        b.set_dispersion(3, 1.0)
+    with pytest.raises(W.OceanError):
+        b.set_dispersion(1, 0.0)
     b.close()
 
 

@@ -160,6 +160,10 @@ class OceanBatch:
     def set_mode(self, mode: int):
         _abi.check(self._L.ocean_set_mode(self._h, mode), "ocean_set_mode")
 
+    def set_dispersion(self, kind: int, param: float = 0.0):
+        """0 deep water (reference), 1 finite depth (param = D), 2 capillary (param = L); next prepare()."""
+        _abi.check(self._L.ocean_set_dispersion(self._h, kind, param), "ocean_set_dispersion")
+
     def set_spectrum_precision(self, bits: int):
         _abi.check(self._L.ocean_set_spectrum_precision(self._h, bits), "ocean_set_spectrum_precision")
 

@@ -34,7 +34,7 @@ SYMBOLS = [
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
     "ocean_read_maps_async", "ocean_device_maps", "ocean_bind_output",
     "ocean_displace_grid", "ocean_read_grid", "ocean_device_grid",
-    "ocean_set_mode", "ocean_set_spectrum_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
+    "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
     "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
 ]
 
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         "ocean_read_grid": (i32, [P, C.c_void_p, C.c_void_p]),
         "ocean_device_grid": (i32, [P, C.POINTER(P), C.POINTER(P), C.POINTER(u32)]),
         "ocean_set_mode": (i32, [P, i32]),
+        "ocean_set_dispersion": (i32, [P, i32, f32]),
         "ocean_set_spectrum_precision": (i32, [P, i32]),
         "ocean_set_pipeline_depth": (i32, [P, i32]),
         "ocean_stream": (P, [P]),

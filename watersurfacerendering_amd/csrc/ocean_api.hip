@@ -43,6 +43,8 @@ struct ocean_ctx {
     int depth = 1;
     uint64_t frame_ctr = 0;
     bool have_frame = false;        // a frame has been enqueued since the last ocean_prepare
+    int dispersion = 0;             // ocean_set_dispersion
+    float dispersion_param = 0.0f;
     int last_set = 0;
 
     std::vector<ocean_params> params;
@@ -321,6 +323,8 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         tp[i].base_freq = (float)((double)2.0f * M_PI / (double)p.anim_period);   // .cpp:486-490
         tp[i].length = p.tile_length;
         tp[i].pad_ = 0.0f;
+        tp[i].dispersion = c->dispersion;
+        tp[i].dispersion_param = c->dispersion_param;
         tp[i].seed = seed + i;
         lam[i] = p.lambda;
     }
@@ -725,6 +729,15 @@ int ocean_read_xi(ocean_t* c, uint32_t tile, float* xi)
     const size_t n2 = (size_t)c->n * c->n;
     SYNC_ALL(c);
     HIP_TRY(hipMemcpy(xi, c->xi + tile * n2, n2 * sizeof(float2), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int ocean_set_dispersion(ocean_t* c, int kind, float param)
+{
+    if (!c || kind < OCEAN_DISPERSION_DEEP || kind > OCEAN_DISPERSION_CAPILLARY) return OCEAN_E_INVALID;
+    if (kind != OCEAN_DISPERSION_DEEP && !(param > 0.0f)) return OCEAN_E_INVALID;
+    c->dispersion = kind;
+    c->dispersion_param = param;
     return OCEAN_OK;
 }
 

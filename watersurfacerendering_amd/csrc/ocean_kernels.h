@@ -88,6 +88,8 @@ struct TileParams {          // device copy of one tile's properties
     float damping;           // (.cpp:502-505)
     float base_freq;         // 2 pi / T as float (.cpp:486-490)
     float length;            // tile length L
+    int dispersion;          // 0 deep water (.h:290-293), 1 finite depth D (.h:301-304), 2 capillary L (.h:312-315)
+    float dispersion_param;
     float pad_;
     uint64_t seed;
 };
@@ -207,7 +209,14 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
         const float s = 1.0f / sqrtf(2.0f);
         a.x = (s * g.x) * sp;                         // .h:237-243
         a.y = (s * g.y) * sp;
-        w = floorf(sqrtf(9.81f * k) / p.base_freq) * p.base_freq;   // .h:284-297
+        float disp;                                   // the relation the reference calls, or one of the two it only defines
+        if (p.dispersion == 1)        // sqrt(g k tanh(k D)): in double, rounded once (tanhf differs between libms)
+            disp = (float)sqrt((double)(9.81f * k) * tanh((double)k * (double)p.dispersion_param));
+        else if (p.dispersion == 2)   // sqrt(g k (1 + k^2 L^2))
+            disp = sqrtf(9.81f * k * (1.0f + k * k * p.dispersion_param * p.dispersion_param));
+        else
+            disp = sqrtf(9.81f * k);
+        w = floorf(disp / p.base_freq) * p.base_freq;   // .h:284-287
     }
     h0[tile * n2 + i] = a;
     omega[tile * n2 + i] = w;
