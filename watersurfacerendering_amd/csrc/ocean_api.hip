@@ -83,28 +83,31 @@ struct ocean_ctx {
     hipEvent_t mark_ev[MAXD][4] = {};   // per-launch timing in pipelined mode
 };
 
+static void free_set(ocean_ctx* c, int i);
+
 static void free_device(ocean_ctx* c)
 {
     void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->toff, c->lambda, c->tparams, c->xi,
                     c->h0h, c->h0_inv_scale, c->h0_maxbits};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    for (int i = 0; i < MAXD; ++i) {
-        void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
-        for (void* b : per) if (b) (void)hipFree(b);
-        if (c->mm_host[i]) (void)hipHostFree(c->mm_host[i]);
-        c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr;
-        c->dispN[i] = nullptr; c->nrmN[i] = nullptr; c->mm_host[i] = nullptr;
-    }
+    for (int i = 0; i < MAXD; ++i) free_set(c, i);
     c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr;
     c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
     c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr;
     c->prepared = false;
 }
 
-// intermediates + maps of one pipeline chain (allocated on first use)
-static int alloc_set(ocean_ctx* c, int i)
+static void free_set(ocean_ctx* c, int i)
 {
-    if (c->z[i]) return OCEAN_OK;
+    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
+    for (void* b : per) if (b) (void)hipFree(b);
+    if (c->mm_host[i]) (void)hipHostFree(c->mm_host[i]);
+    c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr;
+    c->dispN[i] = nullptr; c->nrmN[i] = nullptr; c->mm_host[i] = nullptr;
+}
+
+static int alloc_set_buffers(ocean_ctx* c, int i)
+{
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     const size_t nu = n / 2 + 1, nup = n / 2 + 8;
     // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
@@ -121,6 +124,16 @@ static int alloc_set(ocean_ctx* c, int i)
     HIP_TRY(hipMalloc(&c->dispN[i], t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->nrmN[i], t * n2 * sizeof(float4)));
     return OCEAN_OK;
+}
+
+// intermediates + maps of one pipeline chain (allocated on first use; all or nothing)
+static int alloc_set(ocean_ctx* c, int i)
+{
+    if (c->nrmN[i]) return OCEAN_OK;               // the last buffer allocated: the set is complete
+    free_set(c, i);                                 // leftovers of an earlier failed attempt
+    const int rc = alloc_set_buffers(c, i);
+    if (rc != OCEAN_OK) free_set(c, i);
+    return rc;
 }
 
 static bool size_ok(uint32_t n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
