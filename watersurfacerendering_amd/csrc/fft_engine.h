@@ -224,15 +224,24 @@ template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() *
 template <int C>
 __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
 
-// Work-item -> (column c, butterfly j) of the LAST stage.  For a batch whose items fill whole
-// waves the 64 lanes of a wave cover 64/C consecutive j of ONE column each, so a wave's store
-// instruction writes 64/C consecutive outputs per column contiguously (whole 128-byte lines
-// per 16-lane group) instead of C-interleaved 64-byte pieces; otherwise c is fastest, as in
-// the other stages.
-template <int N, int C, int R>
+// Work-item -> (column c, butterfly j) of the LAST stage.  Two lane layouts for a batch whose
+// items fill whole waves:
+//   LM = 0  the 64 lanes of a wave cover 64/C consecutive j of EVERY column, so a store
+//           instruction writes 64/C consecutive outputs per column (whole 128-byte lines per
+//           16-lane group) instead of C-interleaved 64-byte pieces;
+//   LM = 1  a wave covers 64 consecutive j of ONE column: one contiguous 1 KiB burst per store
+//           instruction.  With non-temporal map stores (pipelined frames) that is worth
+//           3-4 % of the frame; with plain stores it costs 1 %, so the kernels pick per instantiation.
+// Otherwise c is fastest, as in the other stages.
+template <int N, int C, int R, int LM = 0>
 __device__ __forceinline__ void last_stage_map(int w, int& c, int& j)
 {
     constexpr int ITEMS = (N / R) * C;
+    if constexpr (LM == 1 && ITEMS % (64 * C) == 0 && C > 1) {
+        c = (w / 64) % C;
+        j = (w % 64) + 64 * (w / (64 * C));
+        return;
+    }
     if constexpr (ITEMS % 64 == 0 && 64 % C == 0 && C > 1) {
         constexpr int JB = 64 / C;
         c = (w / JB) % C;
@@ -246,7 +255,7 @@ __device__ __forceinline__ void last_stage_map(int w, int& c, int& j)
 // Base twiddles of every (stage, work item) of one thread, fetched ONCE per kernel
 // into registers (a handful of VGPRs): the table loads then overlap the kernel's
 // first global loads instead of sitting on the critical path of every transform.
-template <int N, int C, int T, class P> struct TwiddleRegs {
+template <int N, int C, int T, class P, int LM = 0> struct TwiddleRegs {
     static constexpr int it_of(int stage) { return ((N / P::r[stage]) * C + T - 1) / T; }
     static constexpr int itmax()
     {
@@ -268,7 +277,7 @@ template <int N, int C, int T, class P> struct TwiddleRegs {
             int j = (wi < ITEMS ? wi : 0) / C;
             if constexpr (STAGE == P::S - 1) {
                 int c_unused;
-                last_stage_map<N, C, R>(wi < ITEMS ? wi : 0, c_unused, j);
+                last_stage_map<N, C, R, LM>(wi < ITEMS ? wi : 0, c_unused, j);
             }
             if constexpr (NS > 1) w[STAGE][u] = tw[(j % NS) * (N / (NS * R))];
             else w[STAGE][u] = make_float2(1.f, 0.f);
@@ -283,7 +292,7 @@ template <int N, int C, int T, class P> struct TwiddleRegs {
 //          serve values it prefetched into registers);  otherwise from LDS
 //   LAST : outputs to out(idx, c, value, u, i) (u, i are unrolled constants);
 //          otherwise to LDS, in place (reads complete -> barrier -> writes)
-template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, class TW, class In, class Out>
+template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, class TW, class In, class Out>
 __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
     [[maybe_unused]] constexpr int STAMP_BASE = STAGE;
@@ -298,7 +307,7 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             const int w = tid + u * T;
             if (!GUARD || w < ITEMS) {
                 int c, j;
-                last_stage_map<N, C, R>(w, c, j);
+                last_stage_map<N, C, R, LM>(w, c, j);
                 v2 x[R];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -352,16 +361,16 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
     }
 }
 
-template <int N, int C, int T, class P, int STAGE, int NS, class TW, class In, class Out>
+template <int N, int C, int T, class P, int STAGE, int NS, int LM, class TW, class In, class Out>
 __device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
     constexpr int R = P::r[STAGE];
     constexpr bool FIRST = STAGE == 0, LAST = STAGE == P::S - 1;
-    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE>(lds, twr, tid, in, out);
+    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM>(lds, twr, tid, in, out);
     OCEAN_STAMP(10 + 3 * STAGE);
     if constexpr (!LAST) {
         __syncthreads();
-        run_stages<N, C, T, P, STAGE + 1, NS * R>(lds, twr, tid, in, out);
+        run_stages<N, C, T, P, STAGE + 1, NS * R, LM>(lds, twr, tid, in, out);
     }
 }
 
@@ -370,21 +379,21 @@ __device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In&
 // `twr` = TwiddleRegs<N, C, T, P> loaded from the table tw[k] = exp(+2 pi i k / N).
 // The call may start while other waves still read `lds` from a previous call:
 // the first LDS write is preceded by a barrier.
-template <int N, int C, int T, class P = Plan<N>, class In, class Out>
-__device__ __forceinline__ void batch_fft(c32* lds, const TwiddleRegs<N, C, T, P>& twr, int tid, In& in, Out& out)
+template <int N, int C, int T, class P = Plan<N>, int LM = 0, class In, class Out>
+__device__ __forceinline__ void batch_fft(c32* lds, const TwiddleRegs<N, C, T, P, LM>& twr, int tid, In& in, Out& out)
 {
     static_assert(P::product() == N, "radix plan does not match the transform length");
     // Launder the base twiddles: otherwise the compiler hoists the whole power chain
     // (up to 15 complex per stage) out of consecutive transforms and keeps ~90 VGPRs
     // live across them -- recomputing 14 products per butterfly is far cheaper than
     // the occupancy that costs.
-    TwiddleRegs<N, C, T, P> local = twr;
+    TwiddleRegs<N, C, T, P, LM> local = twr;
 #pragma unroll
     for (int s = 0; s < P::S; ++s)
 #pragma unroll
-        for (int u = 0; u < TwiddleRegs<N, C, T, P>::itmax(); ++u)
+        for (int u = 0; u < TwiddleRegs<N, C, T, P, LM>::itmax(); ++u)
             asm volatile("" : "+v"(local.w[s][u].x), "+v"(local.w[s][u].y));
-    run_stages<N, C, T, P, 0, 1>(lds, local, tid, in, out);
+    run_stages<N, C, T, P, 0, 1, LM>(lds, local, tid, in, out);
 }
 
 // Mapping of the FIRST stage: work item w = tid + u*T reads inputs
@@ -399,13 +408,13 @@ template <int N, int C, int T, class P = Plan<N>> struct FirstStage {
 
 // Mapping of the LAST stage: work item w = tid + u*T owns outputs
 // idx = j + i*(N/RL), column c, with j = w / C, c = w % C (k == j there).
-template <int N, int C, int T, class P = Plan<N>> struct LastStage {
+template <int N, int C, int T, class P = Plan<N>, int LM = 0> struct LastStage {
     static constexpr int RL = P::last;
     static constexpr int ITEMS = (N / RL) * C;
     static constexpr int IT = (ITEMS + T - 1) / T;
     static constexpr bool GUARD = (ITEMS % T) != 0;
     static constexpr int STRIDE = N / RL;
-    static __device__ __forceinline__ void map(int w, int& c, int& j) { last_stage_map<N, C, RL>(w, c, j); }
+    static __device__ __forceinline__ void map(int w, int& c, int& j) { last_stage_map<N, C, RL, LM>(w, c, j); }
 };
 
 }  // namespace ocean

@@ -583,7 +583,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    TwiddleRegs<N, C, T, P> twr;
+    constexpr int LM = NTS ? 1 : 0;                       // last-stage lane layout (fft_engine.h): 1 KiB bursts with NT stores
+    TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
     constexpr int HB = HF::NUP / (2 * C);                 // height workgroups
     constexpr int NB = (HF::NU + C - 1) / C;              // normal workgroups
@@ -630,7 +631,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     // ---- NORMAL workgroup ------------------------------------------------------------
     // (writing the two halves of a texel separately -- 8-byte stores, no registers held
     // between the transforms -- was measured 50% slower: the partial lines do not meet in L2)
-    using LS = LastStage<N, C, T, P>;
+    using LS = LastStage<N, C, T, P, LM>;
     const int u0 = xcd_swizzle(blockIdx.x - HB, NB) * C;
     const float2* __restrict__ z1 = a.z + (size_t)tile * HF::Z_TILE + HF::Z_GROUP;
     const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
@@ -704,7 +705,8 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
-    using LS = LastStage<N, C, T, P>;
+    constexpr int LM = NTS ? 1 : 0;                       // as in k_xpass_b
+    using LS = LastStage<N, C, T, P, LM>;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
@@ -713,7 +715,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     const float2* __restrict__ z0 = a.z + (size_t)tile * HF::Z_TILE;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
     float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
-    TwiddleRegs<N, C, T, P> twr;
+    TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
     float hv[LS::IT][LS::RL];
 #pragma unroll
