@@ -104,7 +104,7 @@ struct FrameArgs {
     float2* z;               // [tiles][3][N/2+1][2][NUP] row-transformed pairs: row m, side 0 = columns
                              //   u = 0..N/2, side 1 = columns (N-u)%N, NUP = N/2 + 8 (padded)
     float2* zh;              // [tiles][N/2+1][NUP]      row-transformed height, columns 0..N/2
-    float* hraw;             // [tiles][NUP/8][N][8]     signed raw height, columns 0..N/2, 8-column tiles
+    float* hraw;             // [tiles][NUP][N]          signed raw height of map rows 0..N/2 (+ padding rows)
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
     unsigned* minmax_host;   // [tiles][2]       host-coherent copy, written by the displacement pass
     float4* disp;            // [tiles][N][N]
@@ -321,7 +321,9 @@ template <int N> struct Half {
     static constexpr size_t ZH_TILE = (size_t)NU * NUP;
     static constexpr size_t HRAW_TILE = (size_t)NUP * N;          // floats
 };
-__device__ __forceinline__ unsigned hraw_index(int n, int p, int u) { return (unsigned)(((u >> 3) * n + p) * 8 + (u & 7)); }
+// raw height of map row u at column p: rows of N floats, so that a wave working on one row reads
+// and writes 64 consecutive floats (an 8-row-interleaved layout cost the displacement pass 5 us)
+__device__ __forceinline__ unsigned hraw_index(int n, int p, int u) { return (unsigned)(u * n + p); }
 
 // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give the
 // workgroups that share an XCD (same id % 8) consecutive column blocks: lines
@@ -610,7 +612,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             const float ha = s * v.x, hb = -s * v.y;
             if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
             if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
-            *reinterpret_cast<float2*>(&at32(hraw, hraw_index(N, p, u))) = make_float2(ha, hb);
+            at32(hraw, hraw_index(N, p, u)) = ha;
+            at32(hraw, hraw_index(N, p, u + 1)) = hb;
         };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 #pragma unroll
