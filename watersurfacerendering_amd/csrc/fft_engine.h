@@ -229,9 +229,9 @@ __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >>
 //   LM = 0  the 64 lanes of a wave cover 64/C consecutive j of EVERY column, so a store
 //           instruction writes 64/C consecutive outputs per column (whole 128-byte lines per
 //           16-lane group) instead of C-interleaved 64-byte pieces;
-//   LM = 1  a wave covers 64 consecutive j of ONE column: one contiguous 1 KiB burst per store
-//           instruction.  With non-temporal map stores (pipelined frames) that is worth
-//           3-4 % of the frame; with plain stores it costs 1 %, so the kernels pick per instantiation.
+//   LM = 1  a wave covers 64 consecutive j of ONE column: one contiguous run per store
+//           instruction (1 KiB of float4 texels, 256 B of floats).  The x pass uses this one:
+//           3-6 % of a pipelined frame over LM = 0, and the raw-height rows stream.
 // Otherwise c is fastest, as in the other stages.
 template <int N, int C, int R, int LM = 0>
 __device__ __forceinline__ void last_stage_map(int w, int& c, int& j)

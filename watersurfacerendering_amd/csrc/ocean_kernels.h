@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    constexpr int LM = NTS ? 1 : 0;                       // last-stage lane layout (fft_engine.h): 1 KiB bursts with NT stores
+    constexpr int LM = 1;                                 // last-stage lane layout (fft_engine.h): a wave = one map row, 1 KiB bursts
     TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
     constexpr int HB = HF::NUP / (2 * C);                 // height workgroups
@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
-    constexpr int LM = NTS ? 1 : 0;                       // as in k_xpass_b
+    constexpr int LM = 1;                                 // as in k_xpass_b
     using LS = LastStage<N, C, T, P, LM>;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
