@@ -45,9 +45,9 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 #  * SURVEY.md 8d's model (7 fields, two passes, F = 3.5 complex intermediates, no point
 #    symmetry): 108 B/texel per frame, apportioned to the launches that do that work;
 #    `roofline.achieved` uses this one, as the task statement prescribes.
-#  * what this pipeline actually has to move (half-size intermediates): 76 B/texel per frame.
+#  * what this pipeline actually has to move (half-size intermediates, 16-bit dispersion): 74 B/texel per frame.
 KERNEL_BYTES_SURVEY = {"k_zpass": 40, "k_xpass_b": 40, "k_xpass_disp": 28}
-KERNEL_BYTES_ACTUAL = {"k_zpass": 26, "k_xpass_b": 28, "k_xpass_disp": 22}
+KERNEL_BYTES_ACTUAL = {"k_zpass": 24, "k_xpass_b": 28, "k_xpass_disp": 22}
 FRAME_BYTES_SURVEY = 108.0
 
 

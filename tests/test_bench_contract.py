@@ -22,7 +22,7 @@ def test_byte_model_matches_survey_8d(bench):
     # 12 (h0 + omega) + 16 * 3.5 (intermediates out and in) + 32 (maps) + 8 (height normalisation)
     assert bench.FRAME_BYTES_SURVEY == 12 + 16 * 3.5 + 32 + 8 == 108
     assert sum(bench.KERNEL_BYTES_SURVEY.values()) == 108
-    assert sum(bench.KERNEL_BYTES_ACTUAL.values()) == 76
+    assert sum(bench.KERNEL_BYTES_ACTUAL.values()) == 74
     assert set(bench.KERNEL_BYTES_SURVEY) == set(bench.KERNEL_BYTES_ACTUAL) == {"k_zpass", "k_xpass_b", "k_xpass_disp"}
     assert bench.HBM_PEAK_GBPS == 8000.0
 

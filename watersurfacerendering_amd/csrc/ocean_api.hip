@@ -52,6 +52,10 @@ struct ocean_ctx {
     // device state
     float2* h0 = nullptr;
     float* omega = nullptr;
+    uint16_t* omega_q = nullptr;    // omega / base_freq as 16-bit integers (what the frame kernels read)
+    float* base_freq = nullptr;     // [tiles]
+    unsigned* omega_q_overflow = nullptr;
+    bool omega16 = false;           // every multiple fits 16 bits (decided at ocean_prepare)
     float* k1d = nullptr;
     float2* tw = nullptr;
     float2* z[MAXD] = {};
@@ -87,11 +91,12 @@ static void free_set(ocean_ctx* c, int i);
 
 static void free_device(ocean_ctx* c)
 {
-    void* bufs[] = {c->h0, c->omega, c->k1d, c->tw, c->toff, c->lambda, c->tparams, c->xi,
+    void* bufs[] = {c->h0, c->omega, c->omega_q, c->base_freq, c->omega_q_overflow, c->k1d, c->tw, c->toff, c->lambda, c->tparams, c->xi,
                     c->h0h, c->h0_inv_scale, c->h0_maxbits};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < MAXD; ++i) free_set(c, i);
-    c->h0 = nullptr; c->omega = nullptr; c->k1d = nullptr; c->tw = nullptr;
+    c->h0 = nullptr; c->omega = nullptr; c->omega_q = nullptr; c->base_freq = nullptr; c->omega_q_overflow = nullptr;
+    c->k1d = nullptr; c->tw = nullptr;
     c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
     c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr;
     c->prepared = false;
@@ -144,6 +149,9 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&c->h0, t * n2 * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->omega, t * n2 * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->omega_q, t * n2 * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc(&c->base_freq, t * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->omega_q_overflow, sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->k1d, t * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->tw, n * sizeof(float2)));
     {
@@ -350,7 +358,8 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         dim3 g((unsigned)((n + 255) / 256), (unsigned)t);
         hipLaunchKernelGGL(k_init_k1d, g, dim3(256), 0, stream_of(c, 0), c->k1d, c->tparams, (int)n);
         dim3 g2((unsigned)((n2 + 255) / 256), (unsigned)t);
-        hipLaunchKernelGGL(k_init_spectrum, g2, dim3(256), 0, stream_of(c, 0), c->h0, c->omega,
+        HIP_TRY(hipMemsetAsync(c->omega_q_overflow, 0, sizeof(unsigned), stream_of(c, 0)));
+        hipLaunchKernelGGL(k_init_spectrum, g2, dim3(256), 0, stream_of(c, 0), c->h0, c->omega, c->omega_q, c->base_freq, c->omega_q_overflow,
                            xi_or_null ? (float2*)nullptr : c->xi, xi_or_null ? c->xi : (const float2*)nullptr,
                            c->k1d, c->tparams, (int)n);
     }
@@ -369,6 +378,12 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         HIP_TRY(hipGetLastError());
     }
     SYNC_ALL(c);
+    {
+        unsigned overflow = 1;
+        HIP_TRY(hipMemcpy(&overflow, c->omega_q_overflow, sizeof(unsigned), hipMemcpyDeviceToHost));
+        static const char* const w16_env = getenv("OCEAN_OMEGA16");             // developer override (A/B runs)
+        c->omega16 = overflow == 0 && !(w16_env && atoi(w16_env) == 0);
+    }
     c->seed = seed;
     c->prepared = true;
     c->have_frame = false;
@@ -414,8 +429,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     static bool attr_done_dev[64] = {};             // function attributes are per device
     bool& attr_done = attr_done_dev[c->device & 63];
     if (!attr_done) {
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true>, lds_rows)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false>, lds_b)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
@@ -438,10 +455,11 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #ifdef OCEAN_STAMPS
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
-        if (a.h0h)
-            hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, true>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows, st, a);
-        else
-            hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR>), dim3(gx, tiles), dim3(G::T_ROWS), lds_rows, st, a);
+        const dim3 grid(gx, tiles), block(G::T_ROWS);
+        if (a.h0h && a.omega_q) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, true, true>), grid, block, lds_rows, st, a);
+        else if (a.h0h) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, true, false>), grid, block, lds_rows, st, a);
+        else if (a.omega_q) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, false, true>), grid, block, lds_rows, st, a);
+        else hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, false, false>), grid, block, lds_rows, st, a);
     }
     if (marks) (void)hipEventRecord(marks[1], st);
 #ifdef OCEAN_STAMPS
@@ -482,6 +500,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     hipStream_t st = stream_of(c, set);
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
+    a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.minmax_host = c->mm_host[set];
@@ -881,7 +900,7 @@ const char* ocean_kernel_name(const ocean_t* c, int idx)
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {
     (void)c;
-    return 108;   // SURVEY.md 8d accounting for the 7-field two-pass scheme; this pipeline moves 76 (ocean_kernels.h)
+    return 108;   // SURVEY.md 8d accounting for the 7-field two-pass scheme; this pipeline moves 74 (ocean_kernels.h)
 }
 
 }  // extern "C"

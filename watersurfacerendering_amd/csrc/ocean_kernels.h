@@ -26,9 +26,9 @@
 //   k_xpass_disp part 2, needs the min/max: pair 0 + raw height -> displacement-map rows.
 //   The x axis goes last so that every map row is written as whole contiguous lines.
 //
-// HBM bytes per texel actually moved (this pipeline): 12 (h0, omega) + 14 + 14
-// (half-size intermediates out and in) + 2 + 2 (raw height) + 32 (maps) = 76,
-// against 108 for the straightforward 3.5-transform two-pass scheme the
+// HBM bytes per texel actually moved (this pipeline): 10 (h0 8, dispersion as a 16-bit multiple
+// of the base frequency 2) + 14 + 14 (half-size intermediates out and in) + 2 + 2 (raw height)
+// + 32 (maps) = 74, against 108 for the straightforward 3.5-transform two-pass scheme the
 // roofline accounting of SURVEY.md section 8d assumes.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -97,6 +97,8 @@ struct TileParams {          // device copy of one tile's properties
 struct FrameArgs {
     const float2* h0;        // [tiles][N][N]   base amplitudes h0(k), TRANSPOSED: [n (kx index)][m (kz index)]
     const float* omega;      // [tiles][N][N]   quantised dispersion, same layout
+    const uint16_t* omega_q; // [tiles][N][N]   the same as the integer multiple of base_freq (null: use omega); see k_zpass
+    const float* base_freq;  // [tiles]
     const __half2* h0h;      // [tiles][N][N]   optional fp16 copy of h0 scaled by 1/h0_inv_scale[tile] (null = fp32)
     const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
@@ -180,7 +182,8 @@ __device__ inline float phillips_nc(const TileParams& p, float ux, float uz, flo
     return p.phillips_a * expf(-1.0f / (k2 * l2)) / k4 * cf * expf(-k2 * p.damping * p.damping);
 }
 
-__global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ omega, float2* __restrict__ xi_out,
+__global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ omega, uint16_t* __restrict__ omega_q,
+                                float* __restrict__ base_freq, unsigned* __restrict__ omega_q_overflow, float2* __restrict__ xi_out,
                                 const float2* __restrict__ xi_in, const float* __restrict__ k1d,
                                 const TileParams* __restrict__ tp, int n)
 {
@@ -201,7 +204,8 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
     const float2 g = xi_in ? xi_in[tile * n2 + ref] : gauss_pair(p.seed, ref);
     if (xi_out) xi_out[tile * n2 + ref] = g;
     float2 a = make_float2(0.f, 0.f);
-    float w = 0.f;
+    float w = 0.f, steps = 0.f;
+    if (i == 0) base_freq[tile] = p.base_freq;
     if (k > 0.00001f) {
         const float inv = 1.0f / sqrtf(d);            // glm::normalize (.h:133-136)
         const float ux = kx * inv, uz = kz * inv;
@@ -216,10 +220,15 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
             disp = sqrtf(9.81f * k * (1.0f + k * k * p.dispersion_param * p.dispersion_param));
         else
             disp = sqrtf(9.81f * k);
-        w = floorf(disp / p.base_freq) * p.base_freq;   // .h:284-287
+        steps = floorf(disp / p.base_freq);
+        w = steps * p.base_freq;                         // .h:284-287
     }
     h0[tile * n2 + i] = a;
     omega[tile * n2 + i] = w;
+    // omega is an integer multiple of base_freq: the frame kernels read that integer (2 bytes instead of
+    // 4 per texel) and rebuild the same float, float(steps) * base_freq, unless some multiple needs more bits
+    omega_q[tile * n2 + i] = (uint16_t)(steps < 65536.0f ? (unsigned)steps : 0u);
+    if (!(steps < 65536.0f)) atomicOr(omega_q_overflow, 1u);
 }
 
 // fp16 spectrum variant (BASELINE config 4): h0 stored as half2 scaled per tile so
@@ -432,7 +441,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
 // 1024 and 4096 would spill at that cap and keep the looser one
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
-template <int N, int T, class P = Plan<N>, bool H16 = false>
+template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false>
 __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -452,6 +461,8 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;               // [N], cache-resident table
     const bool col0 = (nb == 0);
     [[maybe_unused]] const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
+    [[maybe_unused]] const float base = W16 ? a.base_freq[tile] : 0.0f;
+    [[maybe_unused]] const uint16_t* __restrict__ oq = a.omega_q + tile * n2;
 
     OCEAN_STAMP(0);
     TwiddleRegs<N, 2, T, P> twr;
@@ -485,7 +496,12 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
                     } else {
                         hv[u] = *reinterpret_cast<const float4*>(h0 + g);
                     }
-                    wv[u] = *reinterpret_cast<const float2*>(om + g);
+                    if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
+                        const unsigned two = *reinterpret_cast<const unsigned*>(oq + g);
+                        wv[u] = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+                    } else {
+                        wv[u] = *reinterpret_cast<const float2*>(om + g);
+                    }
 #endif
                 }
             }
