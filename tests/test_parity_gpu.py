@@ -109,6 +109,22 @@ def test_other_dispersion_relations(n, dispersion):
     b.close()
 
 
+def test_huge_animation_period_uses_fp32_dispersion():
+    """The frame kernels read omega as a 16-bit multiple of the base frequency; with a period so long that the
+    multiples exceed 16 bits (here ~1e5 steps) the context must fall back to the fp32 array."""
+    from oracle import oracle as O
+    n = 64
+    xi = O.gauss_xi_numpy(777, n)
+    o = make_oracle(n, xi, anim_period=4.0e5)
+    assert float(o.omega.max()) / (2 * np.pi / 4.0e5) > 65536
+    b = make_gpu(n, xi[None], anim_period=4.0e5)
+    _, om = b.read_spectrum(0)
+    assert np.array_equal(om, o.omega)
+    for t in (0.0, 1.5, 300.0):
+        check_frame(b, o, t)
+    b.close()
+
+
 @pytest.mark.parametrize("n", [16, 64, 256, 512])
 def test_maps_match_oracle_alt_params(n):
     from oracle import oracle as O
