@@ -9,7 +9,9 @@ unpinned").
 
     python tests/golden/make_golden.py
 
-Each file: xi (n,n,2) f32 input draws, params, per t: amp, min, max, disp, nrm (f32).
+ocean_n*.npz: xi (n,n,2) f32 input draws, params, per t: amp, min, max, disp, nrm (f32).
+sampled_n*.npz (n = 256, 512, 1024): seed, per t: amp, min, max, per-channel mean and max of
+|value|, and 1024 texels sampled by a fixed LCG (index list included).
 """
 import os
 import sys
@@ -54,5 +56,39 @@ def main():
             print("wrote", f"ocean_n{n}_{name}.npz")
 
 
+def lcg_indices(n, count=1024, state=0x2545F491):
+    """Texel sample list of SURVEY.md 8c: a fixed 32-bit LCG (Numerical Recipes constants), indices mod n*n."""
+    idx = np.empty(count, np.int64)
+    for i in range(count):
+        state = (1664525 * state + 1013904223) & 0xFFFFFFFF
+        idx[i] = state % (n * n)
+    return idx
+
+
+def sampled():
+    """SURVEY.md 8c, larger sizes: A/min/max, per-channel mean |value| and 1024 sampled texels per time.
+    The draws are not stored: xi = gauss_xi(seed) is part of the oracle and of the library (same generator)."""
+    for n in (256, 512, 1024):
+        seed = 0x5EED0000 + n
+        xi = O.gauss_xi_numpy(seed, n)
+        o = O.Oracle(n)
+        o.prepare(xi=xi)
+        idx = lcg_indices(n)
+        out = {"seed": np.uint64(seed), "n": np.int32(n), "times": np.array(TIMES, np.float32), "index": idx}
+        for i, t in enumerate(TIMES):
+            amp, d, q = o.compute_waves(t, fft=O.FFT_F64)
+            d, q = d.reshape(-1, 4), q.reshape(-1, 4)
+            out[f"amp{i}"] = np.float32(amp)
+            out[f"min{i}"] = np.float32(o.min_height)
+            out[f"max{i}"] = np.float32(o.max_height)
+            out[f"meanabs{i}"] = np.concatenate([np.abs(d).mean(0, dtype=np.float64), np.abs(q).mean(0, dtype=np.float64)])
+            out[f"maxabs{i}"] = np.concatenate([np.abs(d).max(0), np.abs(q).max(0)]).astype(np.float32)
+            out[f"disp{i}"] = d[idx].astype(np.float32)
+            out[f"nrm{i}"] = q[idx].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, f"sampled_n{n}_default.npz"), **out)
+        print("wrote", f"sampled_n{n}_default.npz")
+
+
 if __name__ == "__main__":
     main()
+    sampled()

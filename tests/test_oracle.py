@@ -202,3 +202,24 @@ def test_golden_fixtures(path):
         for c in range(4):
             assert np.abs(d[..., c] - g[f"disp{i}"][..., c]).max() <= 2e-6 * max(np.abs(d[..., c]).max(), 1e-30)
             assert np.abs(q[..., c] - g[f"nrm{i}"][..., c]).max() <= 2e-6 * max(np.abs(q[..., c]).max(), 1e-30)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "sampled_n256*.npz")) + glob.glob(os.path.join(GOLDEN, "sampled_n512*.npz"))))
+def test_sampled_golden_fixtures(path):
+    """SURVEY.md 8c, larger sizes: amplitude, per-channel statistics and 1024 LCG-sampled texels (1024^2 is
+    checked on the GPU side only, to keep the CPU suite short)."""
+    g = np.load(path)
+    n = int(g["n"])
+    o = O.Oracle(n)
+    o.prepare(xi=O.gauss_xi_numpy(int(g["seed"]), n))
+    idx = g["index"]
+    for i, t in enumerate(g["times"]):
+        amp, d, q = o.compute_waves(float(t), fft=O.FFT_F64)
+        d, q = d.reshape(-1, 4), q.reshape(-1, 4)
+        assert abs(amp - float(g[f"amp{i}"])) <= 1e-6 * amp
+        assert abs(o.min_height - float(g[f"min{i}"])) <= 1e-6 * amp and abs(o.max_height - float(g[f"max{i}"])) <= 1e-6 * amp
+        scale = np.maximum(g[f"maxabs{i}"], 1e-30)
+        mean = np.concatenate([np.abs(d).mean(0, dtype=np.float64), np.abs(q).mean(0, dtype=np.float64)])
+        assert np.all(np.abs(mean - g[f"meanabs{i}"]) <= 1e-6 * scale)
+        assert np.all(np.abs(d[idx] - g[f"disp{i}"]) <= 2e-6 * scale[:4])
+        assert np.all(np.abs(q[idx] - g[f"nrm{i}"]) <= 2e-6 * scale[4:])

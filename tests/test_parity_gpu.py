@@ -179,6 +179,27 @@ def test_golden_fixtures_on_gpu(path):
     b.close()
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "sampled_n*.npz"))))
+def test_sampled_golden_fixtures_on_gpu(path):
+    """SURVEY.md 8c, N = 256, 512, 1024: amplitude, per-channel mean |value| and 1024 LCG-sampled texels of the
+    committed fixtures, with the draws generated ON THE DEVICE from the seed (the fixture holds no xi)."""
+    g = np.load(path)
+    n = int(g["n"])
+    b = make_gpu(n, None, seed=int(g["seed"]))
+    idx = g["index"]
+    for i, t in enumerate(g["times"]):
+        amp = float(b.compute_waves(float(t))[0])
+        d, q = b.read_maps()
+        d, q = d[0].reshape(-1, 4), q[0].reshape(-1, 4)
+        scale = np.maximum(g[f"maxabs{i}"], 1e-30)
+        assert abs(amp - float(g[f"amp{i}"])) <= 2 * TOL_AMP * amp
+        mean = np.concatenate([np.abs(d).mean(0, dtype=np.float64), np.abs(q).mean(0, dtype=np.float64)])
+        assert np.all(np.abs(mean - g[f"meanabs{i}"]) <= TOL * scale)
+        assert np.all(np.abs(d[idx] - g[f"disp{i}"]) <= TOL * scale[:4])
+        assert np.all(np.abs(q[idx] - g[f"nrm{i}"]) <= TOL * scale[4:])
+    b.close()
+
+
 # ---------------------------------------------------------------------------
 # full BASELINE sizes: direct oracle comparison + size-independent properties
 @pytest.mark.parametrize("n", [2048, 4096])
