@@ -54,8 +54,10 @@ FRAME_BYTES_SURVEY = 108.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: the device needs a few hundred frames (tens of ms) to reach its steady state -- 200 frames after 10
+    # warm-up frames measure 60 us/frame, every later batch of 200 measures 53-54 -- and 3000 frames are 0.2 s
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--size", type=int, default=2048, help="tile size N (default: the roofline config, 2048)")
     ap.add_argument("--tiles", type=int, default=1, help="independent tiles per rank per step")
     ap.add_argument("--depth", type=int, default=3, help="frame pipeline depth of the asynchronous API (1 = strictly serial frames)")
@@ -254,10 +256,10 @@ def main():
     # the pipelined regime.
     kern_ms_pipe = None
     if args.depth > 1:
-        _, kern_ms_pipe = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
+        _, kern_ms_pipe = b.time_frames(0.0, DT, 50, min(args.steps, 200), per_kernel=True)
         b.set_pipeline_depth(1)
-    ms_serial, kern_ms = b.time_frames(0.0, DT, 3, min(args.steps, 100), per_kernel=True)
-    serial_us_per_step = ms_serial / min(args.steps, 100) * 1e3
+    ms_serial, kern_ms = b.time_frames(0.0, DT, 50, min(args.steps, 200), per_kernel=True)
+    serial_us_per_step = ms_serial / min(args.steps, 200) * 1e3
     b.set_pipeline_depth(args.depth)
     KERNEL_ORDER = b.kernel_names()
     dom = max(range(3), key=lambda i: kern_ms[i])
@@ -343,21 +345,21 @@ def main():
             b.close()
             torch.cuda.empty_cache()
             # strictly serial frames (what a caller of the synchronous ComputeWaves sees, minus the read-back)
-            extra["2048x2048_serial_frames_depth1"] = measure_config(W, n, tiles, local_rank, 100, 10, depth=1)
+            extra["2048x2048_serial_frames_depth1"] = measure_config(W, n, tiles, local_rank, 1000, 300, depth=1)
             # BASELINE.json configs beside the headline one (parity for all of them: tests/test_parity_gpu.py)
-            extra["512x512_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20)
-            extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 300, 20, depth=4)
-            extra["512x512_choppy5_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 300, 20, mode=1)
-            extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 300, 20, mode=2)
+            extra["512x512_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 2000, 500)
+            extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 2000, 500, depth=4)
+            extra["512x512_choppy5_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 2000, 500, mode=1)
+            extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 2000, 500, mode=2)
             extra["512x512_synchronous_calls"] = measure_sync_calls(W, 512, local_rank)
             extra["2048x2048_synchronous_calls"] = measure_sync_calls(W, 2048, local_rank)
             extra["vertex_stage_512"] = measure_consumer(W, 512, local_rank)
             extra["vertex_stage_2048"] = measure_consumer(W, 2048, local_rank)
-            extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 100, 10)
-            extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 100, 10, depth=2)
-            extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 50, 5)
-            extra["4096x4096_fp32_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 30, 6, depth=2)
-            extra["4096x4096_fp16_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 30, 6, h0_bits=16, depth=2)
+            extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 1000, 300)
+            extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 1000, 300, depth=2)
+            extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 500, 150)
+            extra["4096x4096_fp32_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=2)
+            extra["4096x4096_fp16_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 300, 100, h0_bits=16, depth=2)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(n, args.cpu_seconds)
