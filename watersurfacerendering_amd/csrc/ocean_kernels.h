@@ -52,8 +52,8 @@ __device__ __forceinline__ void store_nt(float4* p, float4 v)
 // Map stores.  The maps are written once and never read back by this pipeline, while the
 // intermediates (Z, hraw) and the spectrum are re-read every frame and fit the 256 MiB
 // memory-side cache: when several frames are in flight a non-temporal map store keeps the
-// output stream from evicting that resident set (2048^2, depth 2: -8 % frame time).  A lone
-// serial frame prefers plain stores (the cache then buffers the write burst: +6 % with
+// output stream from evicting that resident set (2048^2, depth 3: 69 -> 54 us per frame).  A lone
+// serial frame prefers plain stores (the cache then buffers the write burst: +4 % with
 // non-temporal), so the x-pass kernels exist in both forms (template flag NTS) and the host
 // picks per launch.  The texel index is turned into a 32-bit byte offset (N <= 4096: < 2^28)
 // so the store addresses as scalar base + vector offset.
