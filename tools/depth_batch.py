@@ -8,8 +8,8 @@ for depth in depths:
     if os.environ.get('OCEAN_FP16'): b.set_spectrum_precision(16)
     if os.environ.get('OCEAN_MODE'): b.set_mode(int(os.environ['OCEAN_MODE']))
     b.prepare(1); b.set_pipeline_depth(depth)
-    frames = int(os.environ.get("OCEAN_FRAMES", "100"))
-    ms, _ = b.time_frames(0.0, 0.05, int(os.environ.get("OCEAN_WARMUP", "10")), frames, per_kernel=False)
+    frames = int(os.environ.get("OCEAN_FRAMES", "1000"))
+    ms, _ = b.time_frames(0.0, 0.05, int(os.environ.get("OCEAN_WARMUP", "500")), frames, per_kernel=False)
     per = ms / frames * 1e3
     out.append(f"d{depth}={per:.1f}us ({n*n*tiles/per/1e3:.1f} Gtexel/s)")
     b.close()
