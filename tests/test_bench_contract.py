@@ -32,3 +32,16 @@ def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
     assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0
     assert r["cores"] >= 1 and "sample" in r and "FFTW not available" in r["sample"]
     assert r["host"]["nproc"] >= 1
+
+
+def test_committed_traffic_file_matches_the_kernels(bench):
+    """profiles/traffic.json (PMC-derived HBM bytes per launch) must name the kernels bench.py accounts for."""
+    import json
+    import os
+    t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", "traffic.json")))
+    assert set(t) == {k + "@2048" for k in bench.KERNEL_BYTES_SURVEY}
+    n2 = 2048 * 2048
+    for k, v in t.items():
+        own = bench.KERNEL_BYTES_ACTUAL[k.split("@")[0]] * n2
+        assert 0.9 * own <= v["hbm_bytes_per_launch"] <= 1.15 * own, (k, v["hbm_bytes_per_launch"], own)   # no wasted re-reads
+        assert os.path.exists(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), v["source"].split(" ")[0]))
