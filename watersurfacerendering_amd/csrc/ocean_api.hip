@@ -413,7 +413,7 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map */,
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
                                hipStream_t st, hipEvent_t* marks /* 4 events or null */)
 {
     using G = Geo<N>;
@@ -429,10 +429,14 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     static bool attr_done_dev[64] = {};             // function attributes are per device
     bool& attr_done = attr_done_dev[c->device & 63];
     if (!attr_done) {
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, false>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, false>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, false>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true, false>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, true>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, true>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, true>, lds_rows)) != hipSuccess) return e;
+        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true, true>, lds_rows)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false>, lds_b)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
@@ -456,10 +460,19 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
-        if (a.h0h && a.omega_q) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, true, true>), grid, block, lds_rows, st, a);
-        else if (a.h0h) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, true, false>), grid, block, lds_rows, st, a);
-        else if (a.omega_q) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, false, true>), grid, block, lds_rows, st, a);
-        else hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, false, false>), grid, block, lds_rows, st, a);
+#define OCEAN_ZPASS(h16, w16, znt) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt>), grid, block, lds_rows, st, a)
+        const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
+        switch (variant) {
+            case 0: OCEAN_ZPASS(false, false, false); break;
+            case 1: OCEAN_ZPASS(false, false, true); break;
+            case 2: OCEAN_ZPASS(false, true, false); break;
+            case 3: OCEAN_ZPASS(false, true, true); break;
+            case 4: OCEAN_ZPASS(true, false, false); break;
+            case 5: OCEAN_ZPASS(true, false, true); break;
+            case 6: OCEAN_ZPASS(true, true, false); break;
+            default: OCEAN_ZPASS(true, true, true); break;
+        }
+#undef OCEAN_ZPASS
     }
     if (marks) (void)hipEventRecord(marks[1], st);
 #ifdef OCEAN_STAMPS
@@ -512,6 +525,12 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.mode = c->mode;
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
     int stream_maps = (c->n >= 4096 || pipe) ? 3 : 0;
+    {   // what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the
+        // 256 MiB memory-side cache: beyond it the intermediates are streamed too (bit 2, see store_z)
+        const double texels = (double)c->tiles * (double)c->n * (double)c->n;
+        const double resident = texels * (10.0 + 16.0 * (pipe ? c->depth : 1));
+        if (resident > 300.0e6) stream_maps |= 4;
+    }
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs): bit mask
     if (stream_env) stream_maps = atoi(stream_env);
     hipError_t e = hipErrorInvalidValue;

@@ -76,6 +76,20 @@ template <class T> __device__ __forceinline__ const T& at32(const T* base, unsig
 {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
 }
+// Intermediate (z-pass output) store.  ZNT = the context's intermediates do not fit the memory-side
+// cache (4096^2, or large batches of tiles with several frames in flight): written non-temporally they
+// at least leave the cache to the spectrum, which is re-read every frame (4096^2: -4 %, 8 x 1024^2 at
+// depth 2: -5 %); where they do fit, a plain store keeps them on chip for the x pass (2048^2: 54 vs 60 us).
+template <bool ZNT> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v)
+{
+    if constexpr (ZNT) {
+        typedef float f2nt __attribute__((ext_vector_type(2)));
+        const f2nt t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<f2nt*>(reinterpret_cast<char*>(base) + idx * 8u));
+    } else {
+        *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+    }
+}
 template <class T> __device__ __forceinline__ T& at32(T* base, unsigned idx)
 {
     return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(T));
@@ -345,7 +359,7 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
 
 // The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
 // column nb == 0, the only one where Tx = S- along the whole column.
-template <int N, int T, class P, bool COL0>
+template <int N, int T, class P, bool COL0, bool ZNT>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
                                                  const TwiddleRegs<N, 2, T, P>& twr, float kx, float sm0, int tid,
                                                  int tile, int nb)
@@ -387,7 +401,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #endif
             // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored
             // positions 0 and N/2 exist on side 0 only: the x pass knows)
-            at32(zt, (unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))) = v;
+            store_z<ZNT>(zt, (unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -413,10 +427,10 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (p <= N / 2) at32(zh, (unsigned)p) = v;          // real input: other half is the conjugate
+                if (p <= N / 2) store_z<ZNT>(zh, (unsigned)p, v);     // real input: other half is the conjugate
                 return;
             }
-            at32(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p)))) = v;
+            store_z<ZNT>(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -441,7 +455,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
 // 1024 and 4096 would spill at that cap and keep the looser one
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
-template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false>
+template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false>
 __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -538,8 +552,8 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     __syncthreads();
     OCEAN_STAMP(1);
 
-    if (col0) zpass_transforms<N, T, P, true>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
-    else zpass_transforms<N, T, P, false>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    if (col0) zpass_transforms<N, T, P, true, ZNT>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_transforms<N, T, P, false, ZNT>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
 }
 
 template <int N> constexpr size_t zpass_lds_bytes()
