@@ -362,8 +362,9 @@ def main():
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 1000, 300)
             extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 1000, 300, depth=2)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 500, 150)
-            extra["4096x4096_fp32_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=2)
-            extra["4096x4096_fp16_spectrum_depth2"] = measure_config(W, 4096, 1, local_rank, 300, 100, h0_bits=16, depth=2)
+            extra["1024x1024_batch8_per_gpu_share_of_config5_depth2"] = measure_config(W, 1024, 8, local_rank, 500, 150, depth=2)
+            extra["4096x4096_fp32_spectrum_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3)
+            extra["4096x4096_fp16_spectrum_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, h0_bits=16, depth=3)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(n, args.cpu_seconds)
