@@ -215,13 +215,14 @@ int ocean_read_xi(ocean_t* ctx, uint32_t tile, float* xi);
 int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
                       float* ms_total, float* ms_kernel /* [3] */);
 
-/* Name of the idx-th launch (0..2) of one frame at the context's tile size, in the
- * order ocean_time_frames reports them: "k_zpass", then "k_xpass_b" + "k_xpass_disp"
- * (N <= 2048) or "k_xpass_height" + "k_xpass_maps" (N = 4096).  NULL if idx is out of range. */
+/* Name of the idx-th launch (0..2) of one frame, in the order ocean_time_frames reports
+ * them: "k_zpass", "k_xpass_b", "k_xpass_disp" at every tile size.  NULL if idx is out of range. */
 const char* ocean_kernel_name(const ocean_t* ctx, int idx);
 
-/* Algorithmic HBM bytes per texel of the implemented pipeline (SURVEY.md
- * section 8d accounting; 108 for the seven-field mode).                          */
+/* HBM bytes per texel this pipeline has to move for one seven-field frame at the context's
+ * precision settings (74 with the fp32 spectrum: 10 in, 14 + 14 half-size intermediates out
+ * and in, 2 + 2 raw height, 32 maps).  SURVEY.md section 8d prices a plain 3.5-transform
+ * two-pass scheme at 108; bench.py reports that figure separately, labelled as a model.     */
 int ocean_algorithmic_bytes_per_texel(const ocean_t* ctx);
 
 #ifdef __cplusplus

@@ -46,6 +46,9 @@ struct ocean_ctx {
     int dispersion = 0;             // ocean_set_dispersion
     float dispersion_param = 0.0f;
     int last_set = 0;
+    uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
+    bool lambda_uniform = true;
+    bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)
 
     std::vector<ocean_params> params;
     uint64_t seed = 0;
@@ -88,6 +91,7 @@ struct ocean_ctx {
 };
 
 static void free_set(ocean_ctx* c, int i);
+static hipStream_t stream_of(const ocean_ctx* c, int set);
 
 static void free_device(ocean_ctx* c)
 {
@@ -119,9 +123,11 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     HIP_TRY(hipMalloc(&c->z[i], t * 3 * nu * 2 * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->hraw[i], t * nup * n * sizeof(float)));
-    HIP_TRY(hipMemset(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2)));
-    HIP_TRY(hipMemset(c->zh[i], 0, t * nu * nup * sizeof(float2)));
-    HIP_TRY(hipMemset(c->hraw[i], 0, t * nup * n * sizeof(float)));
+    // zero-fill ON THE CHAIN'S OWN STREAM: the chain streams are non-blocking (no implicit ordering with the
+    // null stream), and the first z pass of the chain is enqueued right behind this
+    HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
+    HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
+    HIP_TRY(hipMemsetAsync(c->hraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
     HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
     // the displacement pass also drops the final min/max keys into this host-coherent buffer, so the
     // synchronous ComputeWaves needs one stream synchronisation and no device-to-host copy
@@ -292,16 +298,14 @@ int ocean_get_params(const ocean_t* c, uint32_t tile, ocean_params* p)
 
 int ocean_set_lambda(ocean_t* c, uint32_t tile, float lambda)
 {
+    // SetLambda (.cpp:497-500): host state only.  The value reaches the device with the next frame: by value in
+    // the launch arguments when every tile has the same lambda (always so for a single tile), otherwise through
+    // one upload of the per-tile array at that frame -- a GUI "Apply" of several setters never drains the device.
     if (!c) return OCEAN_E_INVALID;
     if (tile != OCEAN_ALL_TILES && tile >= c->tiles) return OCEAN_E_INVALID;
-    std::vector<float> l(c->tiles);
-    for (uint32_t i = 0; i < c->tiles; ++i) {
+    for (uint32_t i = 0; i < c->tiles; ++i)
         if (tile == OCEAN_ALL_TILES || tile == i) c->params[i].lambda = lambda;
-        l[i] = c->params[i].lambda;
-    }
-    HIP_TRY(hipSetDevice(c->device));
-    SYNC_ALL(c);
-    HIP_TRY(hipMemcpy(c->lambda, l.data(), c->tiles * sizeof(float), hipMemcpyHostToDevice));
+    c->lambda_dirty = true;
     return OCEAN_OK;
 }
 
@@ -318,7 +322,8 @@ int ocean_set_tile_size(ocean_t* c, uint32_t tile_size)
     c->ext_disp = nullptr; c->ext_nrm = nullptr;
     int rc = alloc_device(c);
     if (rc) return rc;
-    return ocean_set_lambda(c, OCEAN_ALL_TILES, c->params[0].lambda) == OCEAN_OK ? OCEAN_OK : OCEAN_E_HIP;
+    c->lambda_dirty = true;
+    return OCEAN_OK;
 }
 
 uint32_t ocean_tile_size(const ocean_t* c) { return c ? c->n : 0; }
@@ -330,7 +335,6 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     std::vector<TileParams> tp(t);
-    std::vector<float> lam(t);
     for (size_t i = 0; i < t; ++i) {
         const ocean_params& p = c->params[i];
         // SetWindDirection: w * (1/sqrt(dot(w,w)))  (.cpp:476-479)
@@ -347,11 +351,9 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         tp[i].dispersion = c->dispersion;
         tp[i].dispersion_param = c->dispersion_param;
         tp[i].seed = seed + i;
-        lam[i] = p.lambda;
     }
     SYNC_ALL(c);
     HIP_TRY(hipMemcpy(c->tparams, tp.data(), t * sizeof(TileParams), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->lambda, lam.data(), t * sizeof(float), hipMemcpyHostToDevice));
     if (!c->xi) HIP_TRY(hipMalloc(&c->xi, t * n2 * sizeof(float2)));
     if (xi_or_null) HIP_TRY(hipMemcpy(c->xi, xi_or_null, t * n2 * sizeof(float2), hipMemcpyHostToDevice));
     {
@@ -426,9 +428,9 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
-    static bool attr_done_dev[64] = {};             // function attributes are per device
-    bool& attr_done = attr_done_dev[c->device & 63];
-    if (!attr_done) {
+    // function attributes are per device; a context belongs to one device and one thread, so the flag
+    // lives in the context (no process-wide state shared between contexts or threads)
+    if (c->attr_n != (uint32_t)N) {
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, false>, lds_rows)) != hipSuccess) return e;
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, false>, lds_rows)) != hipSuccess) return e;
         if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, false>, lds_rows)) != hipSuccess) return e;
@@ -441,7 +443,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
         if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
-        attr_done = true;
+        c->attr_n = (uint32_t)N;
     }
 #ifdef OCEAN_STAMPS
     // diagnostic: stamps are recorded for ONE kernel of the frame (env OCEAN_DEBUG_STAMP_KERNEL = 0, 1, 2)
@@ -520,7 +522,23 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
     a.toff = c->use_toff ? c->toff : nullptr;
-    a.lambda = c->lambda;
+    {   // choppiness: by value when all tiles agree, else the per-tile device array (uploaded when it changed)
+        if (c->lambda_dirty) {
+            c->lambda_uniform = true;
+            for (uint32_t i = 1; i < c->tiles && c->lambda_uniform; ++i) c->lambda_uniform = c->params[i].lambda == c->params[0].lambda;
+        }
+        const bool uniform = c->lambda_uniform;
+        a.lambda_all = c->params[0].lambda;
+        a.lambda = uniform ? nullptr : c->lambda;
+        if (!uniform && c->lambda_dirty) {
+            int rc_ = sync_all(c);                      // frames in flight still read the old array
+            if (rc_) return rc_;
+            std::vector<float> l(c->tiles);
+            for (uint32_t i = 0; i < c->tiles; ++i) l[i] = c->params[i].lambda;
+            HIP_TRY(hipMemcpy(c->lambda, l.data(), c->tiles * sizeof(float), hipMemcpyHostToDevice));
+        }
+        c->lambda_dirty = false;
+    }
     a.t = t;
     a.mode = c->mode;
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
@@ -872,8 +890,10 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
                 if (j >= nsets && (rc = collect(set))) return rc;
                 if ((rc = enqueue_frame(c, t0 + dt * (float)(warmup + j), true, c->mark_ev[set]))) return rc;
             }
-            for (int k = 0; k < (frames < nsets ? frames : nsets); ++k) {
-                const int set = (int)((c->frame_ctr + (uint64_t)k) % (uint64_t)c->depth);
+            // the frames still in flight are the last min(frames, nsets) ones, oldest first
+            const int outstanding = frames < nsets ? frames : nsets;
+            for (int k = 0; k < outstanding; ++k) {
+                const int set = (int)((c->frame_ctr - (uint64_t)outstanding + (uint64_t)k) % (uint64_t)c->depth);
                 if ((rc = collect(set))) return rc;
             }
         }
@@ -918,8 +938,11 @@ const char* ocean_kernel_name(const ocean_t* c, int idx)
 
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {
-    (void)c;
-    return 108;   // SURVEY.md 8d accounting for the 7-field two-pass scheme; this pipeline moves 74 (ocean_kernels.h)
+    // what THIS pipeline has to move per texel in the seven-field fp32 mode (ocean_kernels.h):
+    // 8 (h0) + 2 (16-bit dispersion; 4 when the fp32 array is needed) + 14 + 14 (half-size intermediates out and
+    // in) + 2 + 2 (raw height) + 32 (maps).  SURVEY.md 8d's model of a plain 3.5-transform two-pass scheme is 108.
+    if (!c) return 74;
+    return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0);
 }
 
 }  // extern "C"

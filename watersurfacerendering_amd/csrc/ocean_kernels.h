@@ -126,7 +126,8 @@ struct FrameArgs {
     float4* disp;            // [tiles][N][N]
     float4* nrm;             // [tiles][N][N]
     const float* toff;       // [tiles] or null
-    const float* lambda;     // [tiles]
+    const float* lambda;     // [tiles], or null: every tile uses lambda_all
+    float lambda_all;
     float t;
     int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only)
 };
@@ -769,7 +770,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     const float mn = key_float(kmn);
     const float mx = key_float(kmx);
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
-    const float lambda = a.lambda[tile];
+    const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
     auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z0, nf, u0 + c, -1.0f); };
     auto out = [&](int p, int c, c32 v, int u, int i) {
         const int q = u0 + c;
