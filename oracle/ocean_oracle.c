@@ -47,8 +47,36 @@
 #define ORACLE_MODE_CHOPPY5 1   /* h, Dx, Dz, slope-x, slope-z; normal.zw = 0        */
 #define ORACLE_MODE_HEIGHT1 2   /* height only; disp.xz = 0, normal = 0              */
 
-#define ORACLE_FFT_F32 0        /* reference shape: float FFTs                        */
+#define ORACLE_FFT_F32 0        /* reference shape: float FFTs, one thread per 2-D transform */
 #define ORACLE_FFT_F64 1        /* float front end, FFT + pack in double              */
+#define ORACLE_FFT_F32_TEAM 2   /* float FFTs work-shared by every thread (not the reference's shape: the strong CPU baseline) */
+#define ORACLE_FFT_FFTW 3       /* libfftw3f loaded at run time, the reference's plans (WSTessendorf.cpp:191-232); only if present */
+
+/* FFTW 3 (float) entry points, resolved with dlopen when the host has the library.  The reference links
+ * FFTW 3.3.10 (CMakeLists.txt:157-179); nothing on the build image provides it, so this path is taken only
+ * on a host that does.  Constants from FFTW's public API: FFTW_BACKWARD = +1, FFTW_MEASURE = 0. */
+#include <dlfcn.h>
+typedef void* (*fftwf_plan_dft_2d_fn)(int, int, void*, void*, int, unsigned);
+typedef void (*fftwf_execute_fn)(void*);
+typedef void (*fftwf_destroy_plan_fn)(void*);
+static struct { int tried; void* so; fftwf_plan_dft_2d_fn plan; fftwf_execute_fn exec; fftwf_destroy_plan_fn destroy; } g_fftw;
+int oracle_fftw_available(void)
+{
+    if (!g_fftw.tried) {
+        g_fftw.tried = 1;
+        const char* names[] = { "libfftw3f.so.3", "libfftw3f.so", NULL };
+        for (int i = 0; names[i] && !g_fftw.so; ++i) g_fftw.so = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (g_fftw.so) {
+            g_fftw.plan = (fftwf_plan_dft_2d_fn)dlsym(g_fftw.so, "fftwf_plan_dft_2d");
+            g_fftw.exec = (fftwf_execute_fn)dlsym(g_fftw.so, "fftwf_execute");
+            g_fftw.destroy = (fftwf_destroy_plan_fn)dlsym(g_fftw.so, "fftwf_destroy_plan");
+            if (!g_fftw.plan || !g_fftw.exec || !g_fftw.destroy) { dlclose(g_fftw.so); g_fftw.so = NULL; }
+        }
+    }
+    return g_fftw.so != NULL;
+}
+
+int oracle_num_threads(void);
 
 typedef struct oracle_ctx {
     /* properties: WSTessendorf.h:181-199 */
@@ -82,6 +110,8 @@ typedef struct oracle_ctx {
     cpx_d* fd;               /* 7*n*n, only for ORACLE_FFT_F64 */
     cpx_f* work_f;           /* 7 * 17n */
     cpx_d* work_d;
+    cpx_f* work_team;        /* threads * 17n, ORACLE_FFT_F32_TEAM */
+    void* fftw_plans[7];     /* ORACLE_FFT_FFTW: one in-place plan per field, like WSTessendorf.cpp:191-232 */
 } oracle_ctx;
 
 /* ------------------------------------------------------------------------ */
@@ -151,7 +181,10 @@ void oracle_wind(const oracle_ctx* c, float* out2) { out2[0] = c->wind_x; out2[1
 static void free_buffers(oracle_ctx* c)
 {
     free(c->kvec); free(c->kunit); free(c->h0); free(c->h0c); free(c->omega); free(c->xi);
-    free(c->disp); free(c->nrm); free(c->ff); free(c->fd); free(c->work_f); free(c->work_d);
+    free(c->disp); free(c->nrm); free(c->ff); free(c->fd); free(c->work_f); free(c->work_d); free(c->work_team);
+    c->work_team = NULL;
+    for (int f = 0; f < 7; ++f)
+        if (c->fftw_plans[f]) { g_fftw.destroy(c->fftw_plans[f]); c->fftw_plans[f] = NULL; }
     c->kvec = c->kunit = c->h0 = c->h0c = c->omega = c->xi = c->disp = c->nrm = NULL;
     c->ff = NULL; c->fd = NULL; c->work_f = NULL; c->work_d = NULL;
     plan1d_free_f(&c->pf); plan1d_free_d(&c->pd);
@@ -329,6 +362,16 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
         if (!c->fd || !c->work_d) return NAN;
     }
 
+    if (fft_kind == ORACLE_FFT_F32_TEAM && !c->work_team) {
+        c->work_team = (cpx_f*)malloc((size_t)oracle_num_threads() * 17 * n * sizeof(cpx_f));
+        if (!c->work_team) return NAN;
+    }
+    if (fft_kind == ORACLE_FFT_FFTW) {
+        if (!oracle_fftw_available()) return NAN;
+        for (int f = 0; f < 7; ++f)      /* SetupFFTW, .cpp:191-232: in place, FFTW_BACKWARD, FFTW_MEASURE (planning clobbers the arrays: done before they are filled) */
+            if (!c->fftw_plans[f]) c->fftw_plans[f] = g_fftw.plan((int)n, (int)n, c->ff + (size_t)f * n2, c->ff + (size_t)f * n2, +1, 0u);
+    }
+
     /* :289-290 -- max starts at numeric_limits<float>::min() (= FLT_MIN > 0) */
     float master_max = FLT_MIN;
     float master_min = FLT_MAX;
@@ -373,6 +416,11 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
             #pragma omp for schedule(dynamic, 1)
             for (int f = 0; f < nfields; ++f)
                 fft2d_f(&c->pf, c->ff + (size_t)f * n2, c->work_f + (size_t)f * 17 * n);
+        } else if (fft_kind == ORACLE_FFT_F32_TEAM) {
+            fft2d_team_f(&c->pf, c->ff, nfields, c->work_team + (size_t)omp_get_thread_num() * 17 * n);
+        } else if (fft_kind == ORACLE_FFT_FFTW) {
+            #pragma omp for schedule(dynamic, 1)     /* omp sections of .cpp:338-367: one fftwf_execute per field */
+            for (int f = 0; f < nfields; ++f) g_fftw.exec(c->fftw_plans[f]);
         } else {
             #pragma omp for schedule(dynamic, 1)
             for (int f = 0; f < nfields; ++f) {

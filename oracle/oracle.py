@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libocean_oracle.so")
 
 MODE_FULL7, MODE_CHOPPY5, MODE_HEIGHT1 = 0, 1, 2
-FFT_F32, FFT_F64 = 0, 1
+FFT_F32, FFT_F64, FFT_F32_TEAM, FFT_FFTW = 0, 1, 2, 3     # see ocean_oracle.c
 
 
 def build(force: bool = False) -> str:
@@ -70,6 +70,7 @@ def lib() -> C.CDLL:
         L.oracle_wind.argtypes = [P, C.POINTER(C.c_float)]
         L.oracle_gauss_pair.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_fftw_available.restype = C.c_int
         L.oracle_fft2d_f32.argtypes = [C.c_int, C.c_void_p]
         L.oracle_fft2d_f64.argtypes = [C.c_int, C.c_void_p]
         _lib = L

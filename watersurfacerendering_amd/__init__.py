@@ -68,13 +68,16 @@ class OceanBatch:
         return p
 
     def set_params(self, tile: int = _abi.OCEAN_ALL_TILES, **kw):
-        p = self.get_params(0 if tile == _abi.OCEAN_ALL_TILES else tile)
-        for k, v in kw.items():
-            k = "lambda_" if k in ("lambda", "lam") else k
-            if not hasattr(p, k):
-                raise TypeError(f"unknown ocean parameter {k!r}")
-            setattr(p, k, v)
-        _abi.check(self._L.ocean_set_params(self._h, tile, C.byref(p)), "ocean_set_params")
+        """Patch the given fields of one tile, or of EVERY tile (each keeps its other parameters)."""
+        tiles = range(self.tiles) if tile == _abi.OCEAN_ALL_TILES else (tile,)
+        for i in tiles:
+            p = self.get_params(i)
+            for k, v in kw.items():
+                k = "lambda_" if k in ("lambda", "lam") else k
+                if not hasattr(p, k):
+                    raise TypeError(f"unknown ocean parameter {k!r}")
+                setattr(p, k, v)
+            _abi.check(self._L.ocean_set_params(self._h, i, C.byref(p)), "ocean_set_params")
 
     def set_lambda(self, lam: float, tile: int = _abi.OCEAN_ALL_TILES):
         _abi.check(self._L.ocean_set_lambda(self._h, tile, lam), "ocean_set_lambda")
