@@ -4,26 +4,33 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One *step* = one ComputeWaves(t) of the hot path (reference
-WSTessendorf.cpp:284-455) on synthetic input: a 2048 x 2048 tile, all seven
-output fields, reference default parameters, xi from the counter-based RNG
-with seed 0x5EED0000 + tile_index, t_j = 0.05*j.  Inputs (h0,
-omega) are resident in HBM before the timed region; outputs are the two finished
-RGBA32F maps in HBM (D2H read-back is not part of the metric).
+Launched bare with --gpus N > 1 (WORLD_SIZE unset) it starts the N rank processes itself
+(`python -m torch.distributed.run`, as a child, before this process touches a GPU) and exits with
+their status; it never reports an `n_gpus` different from the one asked for.
 
-The K timed steps are K asynchronous ocean_compute_waves_async calls followed by one
-synchronise.  With --depth 3 (default) consecutive frames rotate over three
-independent chains (own stream, own intermediates, own map set), so one frame's first
-pass overlaps the others' map passes; every frame is still computed in full and its
-maps stay addressable until the chain is reused.  --depth 1 = strictly serial frames
-(also reported under extra).  Per-launch durations for the roofline object come from HIP
-events around every launch of serial frames (a second pass of the same frames).
+One *step* = one ComputeWaves(t) of the hot path (reference WSTessendorf.cpp:284-455) on synthetic
+input: a 2048 x 2048 tile, all seven output fields, reference default parameters, xi from the
+counter-based RNG with seed 0x5EED0000 + tile_index, t_j = 0.05*j.  Inputs
+(h0, omega) are resident in HBM before the timed region; outputs are the two finished RGBA32F maps
+in HBM (D2H read-back is not part of the metric).
 
-Multi-GPU: tiles are independent, so every rank synthesises its own tile(s)
-with no data-path collective ("weak" scaling, value = frames of all ranks per
-second).  The north-star's single RCCL gather of the packed maps is measured
-separately after the timed region and reported under "gather" (it is
-xGMI-bound and slower than one GPU's synthesis: DESIGN.md section 6).
+The K timed steps are K asynchronous ocean_compute_waves_async calls followed by one synchronise.
+With --depth 3 (default) consecutive frames rotate over three independent chains (own stream, own
+intermediates, own map set); every frame is still computed in full.  --depth 1 = strictly serial
+frames (also reported under extra).
+
+roofline: per-launch durations are the kernels' own execution times (events attached to the
+dispatches with hipExtLaunchKernelGGL on the launch stream, serial frames so that every kernel has
+the GPU to itself); bytes are what THIS pipeline has to move (74 B/texel: 24 / 28 / 22 per launch),
+with the PMC-measured traffic (profiles/traffic.json) and the rocprofv3 duration of the same
+kernel (profiles/kernel_stats.json) beside them.  SURVEY.md 8d's 108 B/texel figure is reported
+separately and labelled as a model, not traffic.
+
+Multi-GPU: tiles are independent, so every rank synthesises its own tile(s) with no data-path
+collective ("weak" scaling, value = frames of all ranks per second).  The north-star's single RCCL
+gather of the packed maps (ocean_gather_maps: ncclGather from the library's own map buffers) is
+measured after the timed region on BASELINE config 5's share (8 tiles of 1024^2 per rank) and
+reported under "gather": compute only, compute + gather serial, gather overlapped.
 
 Rank 0 prints ONE JSON line.
 """
@@ -32,6 +39,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,18 +49,18 @@ sys.path.insert(0, ROOT)
 
 SEED = 0x5EED0000
 DT = 0.05
-HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Bytes per texel per launch, two accountings:
-#  * SURVEY.md 8d's model (7 fields, two passes, F = 3.5 complex intermediates, no point
-#    symmetry): 108 B/texel per frame, apportioned to the launches that do that work;
-#    `roofline.achieved` uses this one, as the task statement prescribes.
-#  * what this pipeline actually has to move (half-size intermediates, 16-bit dispersion): 74 B/texel per frame.
-KERNEL_BYTES_SURVEY = {"k_zpass": 40, "k_xpass_b": 40, "k_xpass_disp": 28}
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
+# Bytes per texel each launch of THIS pipeline has to move: half-size
+# intermediates, 16-bit dispersion.  roofline.achieved / frac use these.
 KERNEL_BYTES_ACTUAL = {"k_zpass": 24, "k_xpass_b": 28, "k_xpass_disp": 22}
+FRAME_BYTES_ACTUAL = 74.0
+# SURVEY.md 8d's MODEL of a plain two-pass scheme with 3.5 full-size complex intermediates (no point
+# symmetry): 108 B/texel per frame.  Not the traffic of this pipeline; reported as `survey_model_*` only.
+KERNEL_BYTES_SURVEY = {"k_zpass": 40, "k_xpass_b": 40, "k_xpass_disp": 28}
 FRAME_BYTES_SURVEY = 108.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the device needs a few hundred frames (tens of ms) to reach its steady state -- 200 frames after 10
@@ -63,40 +72,87 @@ def parse():
     ap.add_argument("--tiles", type=int, default=1, help="independent tiles per rank per step")
     ap.add_argument("--depth", type=int, default=3, help="frame pipeline depth of the asynchronous API (1 = strictly serial frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather measurement at N>1")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget for EACH of the two CPU baseline samples")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary 512^2 / batched measurements")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(n: int, budget_s: float):
-    """The oracle (reference-shaped OpenMP port, own float FFT) timed on the host cores."""
-    from oracle import oracle as O
-    o = O.Oracle(n)
-    o.prepare(seed=SEED)
-    threads = int(O.lib().oracle_num_threads())
+# ---------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` -> N ranks, one per GPU
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(args, argv) -> list:
+    """The child command that runs this script as args.gpus ranks on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """Runs in a process that has NOT initialised a GPU: counts devices (no HIP context), then starts the
+    ranks as a child process and relays their output and status.  Never exec()s."""
+    import torch
+    have = torch.cuda.device_count()        # does not create a HIP context on this image
+    if have < args.gpus and os.environ.get("OCEAN_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {args.gpus} requested but this node has {have} GPU(s); refusing to report "
+              f"a run on fewer GPUs than asked for", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(launch_command(args, argv), env=env)
+    return r.returncode
+
+
+# ---------------------------------------------------------------------------------------------
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def _time_oracle(o, O, fft, budget_s, max_frames=200):
     for j in range(2):
-        o.compute_waves(DT * j, fft=O.FFT_F32, copy=False)
+        o.compute_waves(DT * j, fft=fft, copy=False)
     times = []
     t_start = time.perf_counter()
     j = 0
     while True:
         t0 = time.perf_counter()
-        o.compute_waves(DT * (2 + j), fft=O.FFT_F32, copy=False)
+        o.compute_waves(DT * (2 + j), fft=fft, copy=False)
         times.append(time.perf_counter() - t0)
         j += 1
-        if (time.perf_counter() - t_start >= budget_s and j >= 5) or j >= 200:
+        if (time.perf_counter() - t_start >= budget_s and j >= 5) or j >= max_frames:
             break
     times.sort()
-    med = times[len(times) // 2]
-    model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
+    return times[len(times) // 2], len(times)
+
+
+def cpu_baseline(n: int, budget_s: float):
+    """Two CPU figures on the host cores, same workload, same inputs:
+      cpu_baseline         the oracle in the REFERENCE'S SHAPE (WSTessendorf.cpp:292-455): OpenMP loops around
+                           seven single-threaded 2-D FFTs in parallel -- with FFTW (the reference's plans) when the
+                           host has libfftw3f, else the oracle's own float FFT;
+      cpu_baseline_strong  the same pipeline with the FFT stage work-shared by EVERY core (not the reference's
+                           shape): what a CPU path could reach here.  Speed-ups are quoted against this one.
+    """
+    from oracle import oracle as O
+    o = O.Oracle(n)
+    o.prepare(seed=SEED)
+    threads = int(O.lib().oracle_num_threads())
+    have_fftw = bool(O.lib().oracle_fftw_available())
+    med, cnt = _time_oracle(o, O, O.FFT_FFTW if have_fftw else O.FFT_F32, budget_s)
+    med_s, cnt_s = _time_oracle(o, O, O.FFT_F32_TEAM, budget_s)
     # BASELINE config 1: 256 x 256, height only (1 iFFT), CPU path only (plumbing)
     o1 = O.Oracle(256)
     o1.prepare(seed=SEED)
@@ -107,8 +163,7 @@ def cpu_baseline(n: int, budget_s: float):
         o1.compute_waves(DT * j, mode=O.MODE_HEIGHT1, fft=O.FFT_F32, copy=False)
         t1.append(time.perf_counter() - t0)
     t1.sort()
-    # for scale only: the FFT stage alone with a tuned library FFT (scipy's pocketfft, every core) --
-    # what a faster CPU FFT than the port's would buy the reference; not the reported baseline
+    # for scale only: the FFT stage alone with a tuned library FFT (scipy's pocketfft, every core)
     pocket = None
     try:
         import numpy as np
@@ -124,36 +179,55 @@ def cpu_baseline(n: int, budget_s: float):
                                               "(FFT stage only: no spectrum animation, no pack, no normalisation)"}
     except Exception:
         pass
-    return {
+    host = {"cpu_model": _cpu_model(), "nproc": os.cpu_count(), "omp_max_threads": threads,
+            "note": "stage D of the reference shape (7 single-threaded 2-D FFTs in omp sections) cannot use more than 7 threads"}
+    fft_note = ("FFTW found on this host (libfftw3f, plans as WSTessendorf.cpp:191-232)" if have_fftw else
+                "FFTW not available on this host: baseline is the oracle's own float Stockham FFT")
+    ref_shape = {
         "value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port",
-        "fft_stage_with_library_fft": pocket,
-        "sample": f"{len(times)} frames of the same {n}x{n} 7-field workload after 2 warm-up frames, median "
-                  f"({med * 1e3:.1f} ms/frame); FFTW not available on this host: baseline is the oracle's own "
-                  f"float Stockham FFT in the reference's OpenMP shape (7 single-threaded 2-D FFTs in parallel)",
+        "fft": "fftw3f" if have_fftw else "own",
+        "sample": f"{cnt} frames of the same {n}x{n} 7-field workload after 2 warm-up frames, median "
+                  f"({med * 1e3:.1f} ms/frame); {fft_note}, in the reference's OpenMP shape "
+                  f"(7 single-threaded 2-D FFTs in parallel; {threads} threads for the element-wise loops)",
         "gtexels_per_s": n * n / med * 1e-9,
-        "host": {"cpu_model": model, "nproc": os.cpu_count(), "omp_max_threads": threads,
-                 "note": "stage D of the reference shape (7 single-threaded 2-D FFTs in omp sections) cannot use more than 7 threads"},
+        "fft_stage_with_library_fft": pocket,
+        "host": host,
         "config1_256x256_height_only_cpu_ms": t1[len(t1) // 2] * 1e3,
     }
+    strong = {
+        "value": 1.0 / med_s, "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{cnt_s} full frames of the same workload, median ({med_s * 1e3:.1f} ms/frame): the oracle's pipeline with "
+                  f"the FFT stage (7 x {n} rows, then 7 x {n} columns) work-shared by all {threads} OpenMP threads "
+                  "instead of one thread per 2-D transform -- not the reference's shape, the stronger CPU figure",
+        "gtexels_per_s": n * n / med_s * 1e-9,
+    }
+    return ref_shape, strong
 
 
-def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1, mode=0):
+# ---------------------------------------------------------------------------------------------
+def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1, mode=0, inter_bits=32):
     b = W.OceanBatch(n, tiles, device)
     if h0_bits != 32:
         b.set_spectrum_precision(h0_bits)
+    if inter_bits != 32:
+        b.set_intermediate_precision(inter_bits)
     if mode:
         b.set_mode(mode)
     b.set_pipeline_depth(depth)
     b.prepare(SEED)
     ms, kern = b.time_frames(0.0, DT, warmup, steps, per_kernel=True)
     per = ms / steps * 1e-3
-    KERNEL_ORDER = b.kernel_names()
+    names = b.kernel_names()
+    own = float(b.algorithmic_bytes_per_texel) if mode == 0 else None
     b.close()
-    fb = {0: FRAME_BYTES_SURVEY, 1: 92.0, 2: 44.0}[mode] - (4.0 if h0_bits == 16 else 0.0)   # SURVEY.md 8d per mode
-    return {"size": n, "tiles_per_step": tiles, "pipeline_depth": depth, "mode": ["FULL7", "CHOPPY5", "HEIGHT1"][mode],
-            "frames_per_s": tiles / per, "us_per_step": per * 1e6,
-            "gtexels_per_s": n * n * tiles / per * 1e-9, "algorithmic_GBps": fb * n * n * tiles / per * 1e-9,
-            "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern)}}
+    out = {"size": n, "tiles_per_step": tiles, "pipeline_depth": depth, "mode": ["FULL7", "CHOPPY5", "HEIGHT1", "JACOBIAN"][mode],
+           "frames_per_s": tiles / per, "us_per_step": per * 1e6, "gtexels_per_s": n * n * tiles / per * 1e-9,
+           "kernel_us": {k: v * 1e3 for k, v in zip(names, kern)}}
+    if own is not None:
+        out["own_bytes_per_texel"] = own
+        out["own_bytes_GBps"] = own * n * n * tiles / per * 1e-9
+        out["frac_of_hbm_peak"] = out["own_bytes_GBps"] / HBM_PEAK_GBPS
+    return out
 
 
 def measure_sync_calls(W, n, device, calls=300):
@@ -193,13 +267,147 @@ def measure_consumer(W, n, device, calls=200):
             "what": "ocean_displace_grid back to back on one stream: bilinear REPEAT sampling of both maps, positions + normals out"}
 
 
+def load_profiles_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
+def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, serial_us_per_step, own_bytes_per_texel):
+    """Roofline of the dominant (longest) kernel on this pipeline's own bytes, every kernel beside it."""
+    traffic = load_profiles_json("traffic.json")
+    stats = load_profiles_json("kernel_stats.json")
+    texels = n * n * tiles
+    key = lambda k: f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
+    kernels = {}
+    for k, ms in zip(names, kern_ms):
+        us = ms * 1e3
+        own = KERNEL_BYTES_ACTUAL[k] * texels
+        ent = {"launch_us": us, "own_bytes_per_launch": own, "achieved_GBps": own / (us * 1e-6) * 1e-9}
+        ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBPS
+        tr = traffic.get(key(k))
+        if tr:
+            ent["traffic_bytes_per_launch"] = tr["hbm_bytes_per_launch"]
+            ent["traffic_GBps"] = tr["hbm_bytes_per_launch"] / (us * 1e-6) * 1e-9
+        st = stats.get(key(k))
+        if st:
+            ent["rocprof_launch_us"] = st["avg_us"]
+            ent["event_over_rocprof"] = us / st["avg_us"]
+        kernels[k] = ent
+    dom = max(names, key=lambda k: kernels[k]["launch_us"])
+    d = kernels[dom]
+    tr = traffic.get(key(dom))
+    frame_own = own_bytes_per_texel * texels
+    return {
+        "bound": "hbm", "kernel": dom,
+        "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["frac"],
+        "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+        "traffic_source": tr.get("source") if tr else None,
+        "algorithmic_bytes_per_launch": d["own_bytes_per_launch"],
+        "bytes_model": "this pipeline's own algorithmic bytes per texel: k_zpass 24 (h0 8 + 16-bit dispersion 2 in, half-size "
+                       "intermediates 14 out), k_xpass_b 28 (10 in, raw height 2 + normal map 16 out), k_xpass_disp 22 (6 in, "
+                       "displacement map 16 out); 74 per frame (DESIGN.md section 5)",
+        "launch_us": d["launch_us"],
+        "launch_us_source": "hipExtLaunchKernelGGL start/stop events on the launch stream (kernel execution time), serial frames, "
+                            "mean over the timed frames; rocprofv3 --kernel-trace --stats of the same command: profiles/kernel_stats.json",
+        "rocprof_launch_us": d.get("rocprof_launch_us"),
+        "regime": "serial frames (pipeline depth 1): every kernel has the GPU to itself",
+        "kernels": kernels,
+        "serial_us_per_step": serial_us_per_step,
+        "serial_frame_GBps": frame_own / (serial_us_per_step * 1e-6) * 1e-9,
+        "serial_frame_frac": frame_own / (serial_us_per_step * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+        "pipelined_kernel_us": ({k: v * 1e3 for k, v in zip(names, kern_ms_pipe)} if kern_ms_pipe else None),
+        "pipelined_depth": depth,
+        "frame_bytes_per_texel": own_bytes_per_texel,
+        "frame_GBps": frame_own / (ms_per_step * 1e-3) * 1e-9,
+        "frame_frac": frame_own / (ms_per_step * 1e-3) * 1e-9 / HBM_PEAK_GBPS,
+        "frame_note": "frame_* = the timed (pipelined) region on this pipeline's 74 B/texel; part of that traffic is served by the "
+                      "256 MiB Infinity Cache, so it is a rate of algorithmic bytes, bounded by what that mix can reach (DESIGN.md section 6)",
+        "survey_model": {"what": "SURVEY.md 8d MODEL of a plain 3.5-transform two-pass scheme (108 B/texel; 40 / 40 / 28 per launch): "
+                                 "model bytes divided by measured time -- NOT this pipeline's traffic, may exceed any physical rate",
+                         "frame_bytes_per_texel": FRAME_BYTES_SURVEY,
+                         "frame_model_GBps": FRAME_BYTES_SURVEY * texels / (ms_per_step * 1e-3) * 1e-9,
+                         "dominant_kernel_model_GBps": KERNEL_BYTES_SURVEY[dom] * texels / (d["launch_us"] * 1e-6) * 1e-9},
+    }
+
+
+def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend, red_dev, barrier):
+    """SURVEY.md 8e's three figures on BASELINE config 5's per-GPU share (8 tiles of 1024^2 per rank): compute
+    only, every batch followed by its gather, and the gather overlapped with the next batch (two map sets).  The
+    gather is the library's own ocean_gather_maps (ncclGather x 2 on RCCL, zero-copy from the map buffers)."""
+    n, tiles, reps = 1024, 8, 30
+    b = W.OceanBatch(n, tiles, local_rank)
+    first_tile, _ = wdist.tile_shard(tiles * world, world, rank)
+    b.prepare(SEED + first_tile)
+    uid = wdist.exchange_unique_id(W, src=0)
+    b.comm_init(world, rank, uid)
+    recv = None
+    if rank == 0:
+        recv = torch.empty((2, world, tiles, n, n, 4), dtype=torch.float32, device=dev)
+    rp = (recv[0].data_ptr(), recv[1].data_ptr()) if rank == 0 else (None, None)
+
+    def timed(depth, with_gather, sync_each):
+        b.set_pipeline_depth(depth)
+        for j in range(5):                                   # warm-up (also first touch of every chain's buffers)
+            b.compute_waves_async(DT * j)
+            if with_gather:
+                b.gather_maps(0, *rp)
+        b.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for j in range(reps):
+            b.compute_waves_async(DT * j)
+            if with_gather:
+                b.gather_maps(0, *rp)
+            if sync_each:
+                b.synchronize()
+        b.synchronize(); barrier()
+        return wdist.max_over_ranks((time.perf_counter() - t0) / reps, device=red_dev)
+
+    compute = timed(2, False, False)
+    serial = timed(1, True, True)
+    overlapped = timed(2, True, False)
+    ok = None
+    if rank == 0:                                            # the root's copy of its own tiles equals its maps
+        b.set_pipeline_depth(1)
+        b.compute_waves_async(1.0); b.gather_maps(0, *rp); b.synchronize()
+        import numpy as np
+        d, q = b.read_maps(0, 1)
+        ok = bool(np.array_equal(recv[0, 0, 0].cpu().numpy(), d[0]) and np.array_equal(recv[1, 0, 0].cpu().numpy(), q[0]))
+    b.comm_destroy()
+    b.close()
+    per_rank = tiles * n * n * 4 * 4 * 2
+    total = world * tiles
+    return {"what": "BASELINE config 5 share: 8 tiles of 1024x1024 per rank per step; ocean_gather_maps = ncclGather x 2 "
+                    "(displacement, normal) in one RCCL group from the library's map buffers to rank 0; 'overlapped' = depth 2, "
+                    "the gather of batch j runs on the communication stream beside the synthesis of batch j+1",
+            "transport": "RCCL (librccl loaded by libocean_hip.so), ncclGather" + ("; 1 rank: device-local copy, no xGMI traffic" if world == 1 else ""),
+            "tile_size": n, "tiles_per_rank": tiles, "ranks": world, "bytes_per_rank_per_step": per_rank,
+            "bytes_into_root_per_step": per_rank * (world - 1),
+            "compute_only": {"ms_per_step": compute * 1e3, "tiles_per_s": total / compute},
+            "compute_plus_gather_serial": {"ms_per_step": serial * 1e3, "tiles_per_s": total / serial},
+            "compute_gather_overlapped": {"ms_per_step": overlapped * 1e3, "tiles_per_s": total / overlapped},
+            "root_ingest_GBps_overlapped": per_rank * (world - 1) / overlapped * 1e-9,
+            "root_copy_matches_local_maps": ok}
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))          # nothing in this process has touched a GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different n_gpus")
+
+    # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 (RCCL prints a
+    # version banner there when a communicator is created) is sent to stderr until the line is emitted
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -252,105 +460,35 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * tiles * args.steps / elapsed
 
-    # ---- dominant-kernel roofline, measured live with HIP events on the launch stream.
-    # Per-launch durations only characterise a kernel when it has the GPU to itself, so the
-    # roofline object is measured with serial frames (depth 1; `bench.py --depth 1` under
-    # rocprofv3 reproduces them: profiles/).  At depth > 1 launches of consecutive frames
-    # overlap; those durations are reported beside it, and the frame-level fractions cover
-    # the pipelined regime.
+    # ---- per-kernel durations (kernel execution time from events attached to the dispatches), measured with
+    # serial frames -- a per-launch duration only characterises a kernel that has the GPU to itself; the
+    # pipelined durations are reported beside them
     kern_ms_pipe = None
+    nk = max(3, min(args.steps, 200))
     if args.depth > 1:
-        _, kern_ms_pipe = b.time_frames(0.0, DT, 50, min(args.steps, 200), per_kernel=True)
+        _, kern_ms_pipe = b.time_frames(0.0, DT, 50, nk, per_kernel=True)
         b.set_pipeline_depth(1)
-    ms_serial, kern_ms = b.time_frames(0.0, DT, 50, min(args.steps, 200), per_kernel=True)
-    serial_us_per_step = ms_serial / min(args.steps, 200) * 1e3
+    ms_serial, kern_ms = b.time_frames(0.0, DT, 50, nk, per_kernel=True)
+    serial_us_per_step = ms_serial / nk * 1e3
     b.set_pipeline_depth(args.depth)
-    KERNEL_ORDER = b.kernel_names()
-    dom = max(range(3), key=lambda i: kern_ms[i])
-    dom_name = KERNEL_ORDER[dom]
-    dom_bytes = KERNEL_BYTES_SURVEY[dom_name] * n * n * tiles
-    dom_bytes_actual = KERNEL_BYTES_ACTUAL[dom_name] * n * n * tiles
-    achieved = dom_bytes / (kern_ms[dom] * 1e-3) * 1e-9
-    traffic = None
-    traffic_src = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            ent = tj.get(f"{dom_name}@{n}")
-            if ent:
-                traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
-        except Exception:
-            pass
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": dom_bytes, "launch_us": kern_ms[dom] * 1e3,
-                "regime": "serial frames (pipeline depth 1): HIP events around every launch, one frame at a time; "
-                          "event intervals include ~2.5-3 us of launch/event processing per launch vs rocprofv3",
-                "serial_us_per_step": serial_us_per_step,
-                "serial_frame_frac": FRAME_BYTES_SURVEY * n * n * tiles / (serial_us_per_step * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
-                "pipelined_kernel_us": ({k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern_ms_pipe)} if kern_ms_pipe else None),
-                "pipelined_depth": args.depth,
-                "bytes_model": "SURVEY.md 8d (108 B/texel per frame) apportioned per launch",
-                "achieved_on_this_pipelines_own_bytes": dom_bytes_actual / (kern_ms[dom] * 1e-3) * 1e-9,
-                "own_bytes_per_launch": dom_bytes_actual,
-                "kernel_us": {k: v * 1e3 for k, v in zip(KERNEL_ORDER, kern_ms)},
-                "frame_bytes_per_texel_survey_8d": FRAME_BYTES_SURVEY,
-                "frame_algorithmic_GBps": FRAME_BYTES_SURVEY * n * n * tiles / (ms_per_step * 1e-3) * 1e-9,
-                "frame_frac": FRAME_BYTES_SURVEY * n * n * tiles / (ms_per_step * 1e-3) * 1e-9 / HBM_PEAK_GBPS}
+    names = b.kernel_names()
+    own_bpt = float(b.algorithmic_bytes_per_texel)
+    roofline = roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, args.depth, ms_per_step, serial_us_per_step, own_bpt)
+    b.close()
+    torch.cuda.empty_cache()
 
-    # ---- RCCL gather of the packed maps (north-star exchange step), outside the timed region
+    # ---- the exchange step: RCCL gather of the packed maps, outside the timed region
     gather = None
-    if world > 1 and not args.no_gather:
-        reps = 10
-        # layout [2 (displacement, normal)][tiles][N][N][4] = the library's own tile-major map arrays;
-        # binding caller-owned output makes the frames strictly serial (one map set)
-        maps = torch.empty((2, tiles, n, n, 4), dtype=torch.float32, device=dev)
-        b.bind_output(maps[0].data_ptr(), maps[1].data_ptr())
-        sync(); barrier()
-        tg = time.perf_counter()
-        for j in range(reps):
-            b.compute_waves_async(DT * j)
-            b.synchronize()
-            wdist.gather_maps(maps if backend == "nccl" else maps.cpu(), dst=0)
-            torch.cuda.synchronize()          # the collective runs on its own stream: finish it before `maps` is rewritten
-        barrier()
-        serial = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
-        # the same with the gather of frame j-1 overlapped with the synthesis of frame j (two map sets,
-        # the collective on its own stream): SURVEY.md 8e's third figure
-        maps2 = [maps, torch.empty_like(maps)]
-        sync(); barrier()
-        tg = time.perf_counter()
-        work = None
-        for j in range(reps + 1):
-            if j < reps:
-                cur = maps2[j % 2]
-                b.bind_output(cur[0].data_ptr(), cur[1].data_ptr())
-                b.compute_waves_async(DT * j)
-            if j > 0:
-                prev = maps2[(j - 1) % 2]
-                _, work = wdist.gather_maps(prev if backend == "nccl" else prev.cpu(), dst=0, async_op=True)
-            b.synchronize()
-            if work is not None:
-                work.wait()
-                torch.cuda.synchronize()      # host-side completion: the next frame reuses that map set
-        barrier()
-        overlapped = wdist.max_over_ranks((time.perf_counter() - tg) / reps, device=red_dev)
-        gather = {"what": "every step followed by one torch.distributed.gather (RCCL) of the packed maps to rank 0; "
-                          "'overlapped' = the gather of frame j-1 runs beside the synthesis of frame j (two map sets)",
-                  "backend": backend, "bytes_per_rank": int(maps.numel() * 4), "ms_per_step_serial": serial * 1e3,
-                  "frames_per_s_serial": world * tiles / serial, "ms_per_step_overlapped": overlapped * 1e3,
-                  "frames_per_s_overlapped": world * tiles / overlapped}
+    if not args.no_gather and (backend == "nccl" or world == 1):
+        gather = measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend, red_dev, barrier)
 
     out = None
     if rank == 0:
         extra = {}
         if not args.no_extra and world == 1:
-            b.close()
-            torch.cuda.empty_cache()
             # strictly serial frames (what a caller of the synchronous ComputeWaves sees, minus the read-back)
-            extra["2048x2048_serial_frames_depth1"] = measure_config(W, n, tiles, local_rank, 1000, 300, depth=1)
-            # BASELINE.json configs beside the headline one (parity for all of them: tests/test_parity_gpu.py)
+            extra["2048x2048_serial_frames_depth1"] = measure_config(W, 2048, 1, local_rank, 1000, 300, depth=1)
+            # BASELINE.json configs beside the headline one (parity for all of them: tests/)
             extra["512x512_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 2000, 500)
             extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 2000, 500, depth=4)
             extra["512x512_choppy5_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 2000, 500, mode=1)
@@ -363,11 +501,12 @@ def main():
             extra["512x512_batch16_depth2"] = measure_config(W, 512, 16, local_rank, 1000, 300, depth=2)
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 500, 150)
             extra["1024x1024_batch8_per_gpu_share_of_config5_depth2"] = measure_config(W, 1024, 8, local_rank, 500, 150, depth=2)
-            extra["4096x4096_fp32_spectrum_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3)
-            extra["4096x4096_fp16_spectrum_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, h0_bits=16, depth=3)
-        cpu = None
+            extra["4096x4096_fp32_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3)
+            if hasattr(W.OceanBatch, "set_intermediate_precision"):
+                extra["4096x4096_fp16_intermediates_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3, inter_bits=16)
+        cpu = cpu_strong = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(n, args.cpu_seconds)
+            cpu, cpu_strong = cpu_baseline(n, args.cpu_seconds)
         out = {
             "metric": "ocean frames/s (ComputeWaves, 7 fields -> displacement + normal map)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -383,7 +522,8 @@ def main():
             "gtexels_per_s": n * n * frames_per_s * 1e-9,
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "speedup_vs_cpu_baseline": (frames_per_s / cpu["value"]) if cpu else None,
+            "cpu_baseline_strong": cpu_strong,
+            "speedup_vs_cpu_baseline_strong": (frames_per_s / cpu_strong["value"]) if cpu_strong else None,
             "gather": gather,
             "extra": extra,
         }
@@ -391,7 +531,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)            # C stdio buffers (the RCCL banner) leave through the redirected descriptor
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -42,7 +42,8 @@ enum {
     OCEAN_E_HIP         = -3,   /* a HIP runtime call failed; see ocean_last_hip_error  */
     OCEAN_E_NOT_READY   = -4,   /* ocean_compute_waves before ocean_prepare             */
     OCEAN_E_NOMEM       = -5,
-    OCEAN_E_UNSUPPORTED = -6    /* tile size outside [16, 4096]                         */
+    OCEAN_E_UNSUPPORTED = -6,   /* tile size outside [16, 4096]                         */
+    OCEAN_E_COMM        = -7    /* RCCL call failed / librccl missing; see ocean_last_rccl_error */
 };
 
 typedef struct ocean_ctx ocean_t;
@@ -131,6 +132,26 @@ int ocean_host_register(void* host_ptr, size_t bytes);
 int ocean_host_unregister(void* host_ptr);
 int ocean_read_maps_async(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);
 
+/* The reference's staging-buffer upload in one call.
+ * WaterSurfaceMesh::CopyModelTessDataToStagingBuffer (WaterSurfaceMesh.cpp:701-755) lays its persistently
+ * mapped, HOST_VISIBLE staging buffer out as
+ *     [ vertices | indices | pad to 16 | displacements | normals ]
+ * with the maps at AlignSizeTo(verticesSize + indicesSize, 16) (.cpp:19-22, 721-724) and the normal map
+ * immediately behind the displacement map (.cpp:736-738); UpdateFrameMaps then records two
+ * vkCmdCopyBufferToImage from those offsets (.cpp:642-699).
+ *   ocean_staging_map_offset  that offset, for the caller's VkBufferImageCopy::bufferOffset.
+ *   ocean_read_maps_staging   enqueues the two device-to-host copies of `tile`'s maps of the most recently
+ *                             enqueued frame to mapped_base + offset, ordered behind that frame on its stream;
+ *                             returns at once (register mapped_base's range with ocean_host_register for a true
+ *                             DMA; pageable memory degrades to a blocking copy).  Complete after
+ *                             ocean_synchronize.  *bytes_to_flush (may be NULL) receives offset + 2 * N*N*16:
+ *                             the range the reference then flushes from offset 0 with
+ *                             vkFlushMappedMemoryRanges (vulkan/Buffer.cpp:140-155; a no-op for
+ *                             HOST_COHERENT memory) before it submits the copies.                       */
+size_t ocean_staging_map_offset(size_t vertices_bytes, size_t indices_bytes);
+int ocean_read_maps_staging(ocean_t* ctx, uint32_t tile, void* mapped_base, size_t vertices_bytes,
+                            size_t indices_bytes, size_t* bytes_to_flush);
+
 /* Device pointers of the maps of tile 0 (tile i at +i*N*N*4 floats): zero-copy
  * hand-off to a device-side consumer (interop, RCCL gather).                     */
 int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
@@ -199,6 +220,34 @@ int ocean_device_grid(ocean_t* ctx, void** d_positions, void** d_normals, uint32
  * pipelining; NULL = back to the context's own streams).                         */
 void* ocean_stream(ocean_t* ctx);
 int   ocean_set_stream(ocean_t* ctx, void* hip_stream);
+
+/* ---- multi-GPU: one gather of the packed maps over RCCL ---------------------------------
+ * Not in the reference (a single-process desktop application); this is the exchange step of the
+ * tile-sharded batch mode (BASELINE.json north_star).  Tiles are independent, so the
+ * per-frame synthesis needs no collective: one process per GPU owns a contiguous block of tiles
+ * (one ocean context), and the only communication is every rank sending its finished maps to a
+ * root rank -- ncclGather x 2 (displacement, normal) in one RCCL group, zero-copy from the
+ * context's map buffers, 7 concurrent point-to-point xGMI streams into the root on an 8-GPU node.
+ *   ocean_comm_unique_id  rank 0 creates the 128-byte id; the host program distributes it to the
+ *                         other ranks by any means (MPI, a file, torch.distributed).
+ *   ocean_comm_init       collective: every rank calls it with the same id (ncclCommInitRank on
+ *                         the context's device).
+ *   ocean_gather_maps     enqueues the gather of the most recently enqueued frame's maps on the
+ *                         context's communication stream, ordered behind that frame; returns at
+ *                         once.  On `root` the maps of rank r, tile i arrive at
+ *                         d_recv_*[(r*tiles + i)*N*N*4 floats] (rank-major = global tile order
+ *                         for equal shards); other ranks pass NULL.  With pipeline depth >= 2 the
+ *                         following frames are synthesised into other map sets meanwhile and a
+ *                         chain waits for its gather before rewriting its maps; ocean_synchronize
+ *                         also waits for every gather in flight.
+ * librccl is loaded at the first of these calls, not at library load.                        */
+#define OCEAN_COMM_ID_BYTES 128
+int ocean_comm_unique_id(void* id_out /* OCEAN_COMM_ID_BYTES */);
+int ocean_comm_init(ocean_t* ctx, int nranks, int rank, const void* id /* OCEAN_COMM_ID_BYTES */);
+int ocean_comm_destroy(ocean_t* ctx);
+int ocean_gather_maps(ocean_t* ctx, int root, void* d_recv_disp, void* d_recv_nrm);
+/* ncclResult_t of the most recent failing RCCL call on this thread (0 if none).                 */
+int ocean_last_rccl_error(void);
 
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */

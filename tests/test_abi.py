@@ -46,7 +46,7 @@ def test_abi_version_defaults_and_strerror(abi):
     # WSTessendorf.h:36-43,181
     assert (p.tile_length, p.wind_dir_x, p.wind_dir_y, p.wind_speed, p.anim_period) == (1000.0, 1.0, 1.0, 30.0, 200.0)
     assert p.phillips_const == pytest.approx(3e-7) and p.damping == pytest.approx(0.1) and p.lambda_ == -1.0
-    for code in range(0, -7, -1):
+    for code in range(0, -8, -1):
         assert L.ocean_strerror(code)
     assert b"power of two" in L.ocean_strerror(abi.OCEAN_E_UNSUPPORTED)
 
@@ -71,6 +71,15 @@ def test_argument_checking_without_device(abi):
     assert L.ocean_host_register(None, 16) == abi.OCEAN_E_INVALID
     assert L.ocean_read_maps_async(None, 0, 1, None, None) == abi.OCEAN_E_INVALID
     assert L.ocean_kernel_name(None, 0) is None
+    # staging layout of WaterSurfaceMesh.cpp:19-22,721-724: maps at align16(vertices + indices)
+    assert L.ocean_staging_map_offset(0, 0) == 0 and L.ocean_staging_map_offset(1, 0) == 16
+    assert L.ocean_staging_map_offset(263169 * 32, 1572864 * 4) == (263169 * 32 + 1572864 * 4 + 15) // 16 * 16
+    assert L.ocean_read_maps_staging(None, 0, None, 0, 0, None) == abi.OCEAN_E_INVALID
+    # RCCL gather entry points: argument checks need no device (and no librccl)
+    assert L.ocean_comm_unique_id(None) == abi.OCEAN_E_INVALID
+    assert L.ocean_comm_init(None, 1, 0, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_comm_destroy(None) == abi.OCEAN_E_INVALID
+    assert L.ocean_gather_maps(None, 0, None, None) == abi.OCEAN_E_INVALID
     L.ocean_destroy(None)
 
 

@@ -1,8 +1,13 @@
-"""bench.py's CPU-checkable contract: flag defaults, byte accounting, and the CPU baseline leg on a tiny size."""
+"""bench.py's CPU-checkable contract: flag defaults, byte accounting, the self-launcher and the CPU baseline leg on a tiny size."""
 import importlib
+import json
+import os
+import subprocess
 import sys
 
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture()
@@ -12,36 +17,80 @@ def bench(monkeypatch):
 
 
 def test_defaults_are_one_gpu_and_bounded(bench):
-    a = bench.parse()
+    a = bench.parse([])
     assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0
     assert a.size == 2048 and a.tiles == 1            # BASELINE.json: the 2048x2048 single-tile configuration
     assert 1 <= a.depth <= 8
 
 
-def test_byte_model_matches_survey_8d(bench):
-    # 12 (h0 + omega) + 16 * 3.5 (intermediates out and in) + 32 (maps) + 8 (height normalisation)
+def test_byte_accounting(bench):
+    # this pipeline's own bytes are what roofline.achieved uses ...
+    assert sum(bench.KERNEL_BYTES_ACTUAL.values()) == bench.FRAME_BYTES_ACTUAL == 74
+    # ... SURVEY.md 8d's model is kept beside it: 12 (h0 + omega) + 16 * 3.5 (intermediates out and in) + 32 (maps) + 8
     assert bench.FRAME_BYTES_SURVEY == 12 + 16 * 3.5 + 32 + 8 == 108
     assert sum(bench.KERNEL_BYTES_SURVEY.values()) == 108
-    assert sum(bench.KERNEL_BYTES_ACTUAL.values()) == 74
     assert set(bench.KERNEL_BYTES_SURVEY) == set(bench.KERNEL_BYTES_ACTUAL) == {"k_zpass", "k_xpass_b", "k_xpass_disp"}
     assert bench.HBM_PEAK_GBPS == 8000.0
 
 
-def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
-    r = bench.cpu_baseline(64, 0.5)
-    assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0
-    assert r["cores"] >= 1 and "sample" in r and "FFTW not available" in r["sample"]
-    assert r["host"]["nproc"] >= 1
-
-
-def test_committed_traffic_file_matches_the_kernels(bench):
-    """profiles/traffic.json (PMC-derived HBM bytes per launch) must name the kernels bench.py accounts for."""
-    import json
-    import os
-    t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", "traffic.json")))
-    assert set(t) == {k + "@2048" for k in bench.KERNEL_BYTES_SURVEY}
+def test_roofline_object_uses_own_bytes_and_never_exceeds_peak_on_them(bench):
+    names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
     n2 = 2048 * 2048
-    for k, v in t.items():
-        own = bench.KERNEL_BYTES_ACTUAL[k.split("@")[0]] * n2
-        assert 0.9 * own <= v["hbm_bytes_per_launch"] <= 1.15 * own, (k, v["hbm_bytes_per_launch"], own)   # no wasted re-reads
-        assert os.path.exists(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), v["source"].split(" ")[0]))
+    r = bench.roofline_object(2048, 1, names, [0.027, 0.029, 0.0205], [0.06, 0.05, 0.04], 3, 0.054, 77.0, 74.0)
+    assert r["kernel"] == "k_xpass_b" and r["algorithmic_bytes_per_launch"] == 28 * n2
+    assert r["achieved"] == pytest.approx(28 * n2 / 29e-6 * 1e-9) and r["frac"] == pytest.approx(r["achieved"] / 8000.0)
+    assert r["frame_frac"] == pytest.approx(74 * n2 / 54e-6 * 1e-9 / 8000.0) and r["frame_frac"] < 1.0
+    assert "MODEL" in r["survey_model"]["what"] and "frac" not in r["survey_model"]       # the 108 figure is never a fraction of peak
+    assert set(r["kernels"]) == set(names)
+
+
+def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
+    ref, strong = bench.cpu_baseline(64, 0.3)
+    assert ref["kind"] == "port" and ref["unit"] == "frames/s" and ref["value"] > 0
+    assert ref["cores"] >= 1 and "sample" in ref and ("FFTW not available" in ref["sample"] or ref["fft"] == "fftw3f")
+    assert ref["host"]["nproc"] >= 1
+    assert strong["value"] > 0 and "work-shared" in strong["sample"]
+
+
+def test_committed_profile_summaries_match_the_kernels(bench):
+    """profiles/traffic.json (PMC-derived HBM bytes per launch) and profiles/kernel_stats.json (rocprofv3 durations)
+    must name the kernels bench.py accounts for, and the measured traffic must stay near the algorithmic bytes."""
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert {k + "@2048" for k in bench.KERNEL_BYTES_ACTUAL} <= set(t)
+    n2 = 2048 * 2048
+    for k in bench.KERNEL_BYTES_ACTUAL:
+        v = t[k + "@2048"]
+        own = bench.KERNEL_BYTES_ACTUAL[k] * n2
+        assert 0.85 * own <= v["hbm_bytes_per_launch"] <= 1.15 * own, (k, v["hbm_bytes_per_launch"], own)   # no wasted re-reads
+        assert os.path.exists(os.path.join(ROOT, v["source"].split(" ")[0]))
+    st = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats.json")))
+    for k in bench.KERNEL_BYTES_ACTUAL:
+        assert st[k + "@2048"]["avg_us"] > 0 and os.path.exists(os.path.join(ROOT, st[k + "@2048"]["source"].split(" ")[0]))
+
+
+def test_self_launcher_builds_a_torchrun_child_for_n_ranks(bench):
+    a = bench.parse(["--gpus", "4", "--steps", "7"])
+    cmd = bench.launch_command(a, ["--gpus", "4", "--steps", "7"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+
+
+def test_bare_multi_gpu_run_refuses_instead_of_reporting_fewer_gpus():
+    """`python bench.py --gpus 2` on a node with fewer GPUs must exit non-zero and print no JSON line
+    (round 1 silently ran one rank and printed n_gpus = 1)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("node has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout
+    assert "refusing" in r.stderr
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "refusing" in r.stderr

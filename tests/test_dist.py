@@ -56,6 +56,12 @@ def _worker(rank, world, port, q):
                 local[i, m] = (first + i) * 1000 + m * 100 + torch.arange(n * n * 4, dtype=torch.float32).reshape(n, n, 4) * 1e-3
         gathered, _ = wdist.gather_maps(local, dst=0)
         t = wdist.max_over_ranks(1.0 + rank)
+        # control plane of the native gather: rank 0 creates the RCCL id through the C ABI, every rank receives it
+        import watersurfacerendering_amd as W
+        uid = wdist.exchange_unique_id(W, src=0)
+        ids = [None] * world
+        dist.all_gather_object(ids, uid)
+        assert len(uid) == 128 and all(i == uid for i in ids) and any(uid)
         if rank == 0:
             flat = gathered.reshape(total, 2, n, n, 4)
             ok = all(float(flat[g, m, 0, 0, 0]) == g * 1000 + m * 100 for g in range(total) for m in range(2))

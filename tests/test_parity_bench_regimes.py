@@ -226,3 +226,77 @@ def test_setters_do_not_drain_the_device_and_lambda_reaches_the_next_frame():
     assert [b.get_params(i).lambda_ for i in range(tiles)] == lams
     assert all(b.get_params(i).wind_speed == 12.0 for i in range(tiles))
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# exchange step and upload path
+def test_native_rccl_gather_single_rank_and_staging_layout():
+    """ocean_gather_maps through RCCL with a one-rank communicator (all a 1-GPU box can form: the gather is then a
+    device-local ncclGather), at depth 1 and overlapped at depth 2; and the reference's staging layout
+    [vertices | indices | pad16 | displacements | normals] (WaterSurfaceMesh.cpp:701-755) filled by
+    ocean_read_maps_staging."""
+    import torch
+    import watersurfacerendering_amd as W
+    n, tiles = 256, 3
+    b = make_batch(n, tiles=tiles, seed=91)
+    with pytest.raises(W.OceanError):
+        b.gather_maps(0, 1, 1)                                  # no communicator yet
+    b.comm_init(1, 0, W.comm_unique_id())
+    recv = torch.full((2, 1, tiles, n, n, 4), -7.0, dtype=torch.float32, device="cuda:0")
+    for depth in (1, 2):
+        b.set_pipeline_depth(depth)
+        last = None
+        for j in range(4):                                      # every gather ordered behind its own frame
+            b.compute_waves_async(0.2 * j)
+            b.gather_maps(0, recv[0].data_ptr(), recv[1].data_ptr())
+            last = 0.2 * j
+        b.synchronize()
+        d, q = b.read_maps()
+        got = recv.cpu().numpy()
+        assert np.array_equal(got[0, 0], d) and np.array_equal(got[1, 0], q), depth
+        ref = make_batch(n, tiles=tiles, seed=91)
+        ref.compute_waves(last)
+        d0, q0 = ref.read_maps()
+        assert np.array_equal(d, d0) and np.array_equal(q, q0)
+        ref.close()
+    with pytest.raises(W.OceanError):
+        b.gather_maps(1, None, None)                            # root out of range
+    b.comm_destroy()
+    # staging layout, odd mesh sizes so that the pad matters
+    vb, ib = 1000 * 32 + 4, 2998 * 4
+    off = (vb + ib + 15) // 16 * 16
+    staging = np.full(off + 2 * n * n * 16 + 64, 0xAB, dtype=np.uint8)
+    W.host_register(staging)
+    try:
+        b.set_pipeline_depth(1)
+        b.compute_waves_async(0.6)
+        flush = b.read_maps_staging(staging, vb, ib, tile=1)
+        b.synchronize()
+    finally:
+        W.host_unregister(staging)
+    d, q = b.read_maps(1, 1)
+    assert flush == off + 2 * n * n * 16
+    assert np.all(staging[:off] == 0xAB) and np.all(staging[flush:] == 0xAB)          # mesh data and the tail untouched
+    assert np.array_equal(staging[off:off + n * n * 16].view(np.float32).reshape(n, n, 4), d[0])
+    assert np.array_equal(staging[off + n * n * 16:flush].view(np.float32).reshape(n, n, 4), q[0])
+    b.close()
+
+
+def test_bench_self_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) must itself start two rank processes and report
+    n_gpus = 2.  On a 1-GPU box the ranks share the device through the developer switch OCEAN_BENCH_BACKEND=gloo
+    (RCCL refuses two ranks per device); the driver's multi-GPU runs use the default RCCL backend."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OCEAN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm", "20",
+                        "--size", "512", "--no-extra", "--no-cpu-baseline", "--no-gather"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["roofline"]["frac"] < 1.0 and out["roofline"]["frame_frac"] < 1.0

@@ -1,0 +1,86 @@
+"""Builds the two machine-readable summaries bench.py reads from committed rocprofv3 output (developer tool):
+
+  profiles/kernel_stats.json   average duration per kernel from `rocprofv3 --kernel-trace --stats` CSVs of SERIAL frames
+  profiles/traffic.json        HBM bytes per launch from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
+
+usage: profile_summaries.py stats <kernel_stats.csv> [tiles] ...   (kernels keyed name@N, or name@NxT for T tiles)
+       profile_summaries.py traffic <pmc_summary.txt> <N> [tiles] [fetch_factor]
+Entries are merged into the existing JSON files.  FETCH_SIZE is multiplied by `fetch_factor` (default 2.0: gfx950
+tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md HBM section; tools/ubench/fetchcal.hip calibrates the
+factor for the access widths of these kernels, see profiles/README.md); WRITE_SIZE is taken as read.
+"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ("k_zpass", "k_xpass_b", "k_xpass_disp", "k_xfused", "k_phase_table")
+
+
+def load(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
+def save(name, d):
+    json.dump(d, open(os.path.join(ROOT, "profiles", name), "w"), indent=1, sort_keys=True)
+
+
+def rel(p):
+    return os.path.relpath(os.path.abspath(p), ROOT)
+
+
+def kernel_of(full):
+    m = re.search(r"(k_[a-z_0-9]+)<(\d+)", full)
+    return (m.group(1), int(m.group(2))) if m else (None, None)
+
+
+def stats(path, tiles=1):
+    out = load("kernel_stats.json")
+    acc = {}
+    for row in csv.DictReader(open(path)):
+        k, n = kernel_of(row["Name"])
+        if k not in NAMES:
+            continue
+        a = acc.setdefault((k, n), [0, 0.0])
+        a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
+    for (k, n), (calls, total) in acc.items():
+        key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
+        out[key] = {"avg_us": total / calls * 1e-3, "calls": calls, "source": rel(path) + " (rocprofv3 --kernel-trace --stats, serial frames)"}
+    save("kernel_stats.json", out)
+
+
+def traffic(path, n, tiles=1, fetch_factor=2.0):
+    out = load("traffic.json")
+    cur = None
+    vals = {}
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = kernel_of(line.strip())[0]
+            continue
+        m = re.match(r"\s+(\S+)\s+mean\s+([0-9.]+)", line)
+        if m and cur in NAMES:
+            vals.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+    for k, v in vals.items():
+        if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
+        out[key] = {"hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * fetch_factor + v["WRITE_SIZE"] * 1024),
+                    "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"], "fetch_factor": fetch_factor,
+                    "correction": f"FETCH_SIZE x {fetch_factor} (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md HBM "
+                                  "section, confirmed for these access widths by tools/ubench/fetchcal.hip, profiles/README.md); WRITE_SIZE as read",
+                    "source": rel(path) + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)"}
+    save("traffic.json", out)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1, float(sys.argv[5]) if len(sys.argv) > 5 else 2.0)
+    else:
+        raise SystemExit(__doc__)

@@ -28,7 +28,7 @@ import numpy as np
 from . import _abi
 from ._abi import OceanError, Params, build  # noqa: F401
 
-__all__ = ["WSTessendorf", "OceanBatch", "OceanError", "build", "host_register", "host_unregister"]
+__all__ = ["WSTessendorf", "OceanBatch", "OceanError", "build", "host_register", "host_unregister", "comm_unique_id"]
 
 
 def _is_pow2(n: int) -> bool:
@@ -137,6 +137,34 @@ class OceanBatch:
         _abi.check(self._L.ocean_read_maps_async(self._h, first, count, disp.ctypes.data_as(C.c_void_p),
                                                  nrm.ctypes.data_as(C.c_void_p)), "ocean_read_maps_async")
 
+    def read_maps_staging(self, staging: np.ndarray, vertices_bytes: int, indices_bytes: int, tile: int = 0) -> int:
+        """The reference's staging upload (WaterSurfaceMesh.cpp:701-755): enqueue the copy of the last enqueued
+        frame's maps of `tile` into a byte buffer laid out [vertices | indices | pad16 | displacements | normals].
+        Returns the number of bytes the caller then flushes; valid after synchronize()."""
+        assert staging.dtype == np.uint8 and staging.flags["C_CONTIGUOUS"]
+        n = self.tile_size
+        off = int(self._L.ocean_staging_map_offset(vertices_bytes, indices_bytes))
+        if staging.nbytes < off + 2 * n * n * 16:
+            raise ValueError("staging buffer too small")
+        flush = C.c_size_t()
+        _abi.check(self._L.ocean_read_maps_staging(self._h, tile, staging.ctypes.data_as(C.c_void_p), vertices_bytes,
+                                                   indices_bytes, C.byref(flush)), "ocean_read_maps_staging")
+        return int(flush.value)
+
+    # -- multi-GPU gather of the packed maps (RCCL) ------------------------------------------
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == _abi.OCEAN_COMM_ID_BYTES
+        buf = C.create_string_buffer(unique_id, _abi.OCEAN_COMM_ID_BYTES)
+        _abi.check(self._L.ocean_comm_init(self._h, nranks, rank, buf), "ocean_comm_init")
+
+    def comm_destroy(self):
+        _abi.check(self._L.ocean_comm_destroy(self._h), "ocean_comm_destroy")
+
+    def gather_maps(self, root: int, recv_disp: int | None, recv_nrm: int | None):
+        """Enqueue the RCCL gather of the last enqueued frame's maps to `root` (device pointers of the receive
+        arrays [nranks][tiles][N][N][4] on the root, None elsewhere); asynchronous, see ocean.h."""
+        _abi.check(self._L.ocean_gather_maps(self._h, root, C.c_void_p(recv_disp), C.c_void_p(recv_nrm)), "ocean_gather_maps")
+
     def device_maps(self):
         d, q = C.c_void_p(), C.c_void_p()
         _abi.check(self._L.ocean_device_maps(self._h, C.byref(d), C.byref(q)), "ocean_device_maps")
@@ -208,6 +236,13 @@ class OceanBatch:
     @property
     def algorithmic_bytes_per_texel(self) -> int:
         return int(self._L.ocean_algorithmic_bytes_per_texel(self._h))
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL id created by one rank and handed to every rank's comm_init."""
+    buf = C.create_string_buffer(_abi.OCEAN_COMM_ID_BYTES)
+    _abi.check(_abi.lib().ocean_comm_unique_id(buf), "ocean_comm_unique_id")
+    return buf.raw
 
 
 def host_register(arr: np.ndarray):

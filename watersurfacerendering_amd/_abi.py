@@ -22,6 +22,8 @@ OCEAN_E_HIP = -3
 OCEAN_E_NOT_READY = -4
 OCEAN_E_NOMEM = -5
 OCEAN_E_UNSUPPORTED = -6
+OCEAN_E_COMM = -7
+OCEAN_COMM_ID_BYTES = 128
 OCEAN_ALL_TILES = 0xFFFFFFFF
 OCEAN_MODE_FULL7, OCEAN_MODE_CHOPPY5, OCEAN_MODE_HEIGHT1 = 0, 1, 2
 
@@ -32,7 +34,8 @@ SYMBOLS = [
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
-    "ocean_read_maps_async", "ocean_device_maps", "ocean_bind_output",
+    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_bind_output",
+    "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_gather_maps", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_read_grid", "ocean_device_grid",
     "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
     "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
@@ -41,7 +44,7 @@ SYMBOLS = [
 
 class OceanError(RuntimeError):
     def __init__(self, code: int, what: str):
-        super().__init__(f"{what}: {strerror(code)} (code {code}, hip {last_hip_error()})")
+        super().__init__(f"{what}: {strerror(code)} (code {code}, hip {last_hip_error()}, rccl {last_rccl_error()})")
         self.code = code
 
 
@@ -109,6 +112,13 @@ def lib() -> C.CDLL:
         "ocean_host_register": (i32, [C.c_void_p, C.c_size_t]),
         "ocean_host_unregister": (i32, [C.c_void_p]),
         "ocean_read_maps_async": (i32, [P, u32, u32, C.c_void_p, C.c_void_p]),
+        "ocean_staging_map_offset": (C.c_size_t, [C.c_size_t, C.c_size_t]),
+        "ocean_read_maps_staging": (i32, [P, u32, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "ocean_comm_unique_id": (i32, [C.c_void_p]),
+        "ocean_comm_init": (i32, [P, i32, i32, C.c_void_p]),
+        "ocean_comm_destroy": (i32, [P]),
+        "ocean_gather_maps": (i32, [P, i32, C.c_void_p, C.c_void_p]),
+        "ocean_last_rccl_error": (i32, []),
         "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
         "ocean_bind_output": (i32, [P, P, P]),
         "ocean_displace_grid": (i32, [P, u32, u32, f32, f32, f32]),
@@ -148,6 +158,13 @@ def strerror(code: int) -> str:
 def last_hip_error() -> int:
     try:
         return lib().ocean_last_hip_error()
+    except Exception:  # pragma: no cover
+        return -1
+
+
+def last_rccl_error() -> int:
+    try:
+        return lib().ocean_last_rccl_error()
     except Exception:  # pragma: no cover
         return -1
 

@@ -3,6 +3,9 @@
 // hipFFT/rocFFT, no torch types).  There is no CPU fallback anywhere in this
 // file: without a usable device every entry point returns an error.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is loaded with dlopen when a communicator is asked for
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -87,10 +90,18 @@ struct ocean_ctx {
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
     hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
-    hipEvent_t mark_ev[MAXD][4] = {};   // per-launch timing in pipelined mode
+    hipEvent_t mark_ev[MAXD][6] = {};   // per-launch timing: (start, stop) of each of the three kernels of a frame
+    // ---- packed-map gather over RCCL (ocean_comm_init / ocean_gather_maps)
+    ncclComm_t comm = nullptr;
+    int comm_ranks = 0, comm_rank = -1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t frame_done[MAXD] = {};   // recorded on a chain's stream behind the frame whose maps are gathered
+    hipEvent_t gather_done[MAXD] = {};  // recorded on the communication stream behind that gather
+    bool gather_pending[MAXD] = {};     // the chain's next frame must wait for gather_done before rewriting the maps
 };
 
 static void free_set(ocean_ctx* c, int i);
+static void comm_release(ocean_ctx* c);
 static hipStream_t stream_of(const ocean_ctx* c, int set);
 
 static void free_device(ocean_ctx* c)
@@ -185,6 +196,8 @@ static int sync_all(ocean_ctx* c)
     for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) HIP_TRY(hipStreamSynchronize(c->own[i]));
     if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
+    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    for (bool& p : c->gather_pending) p = false;
     return OCEAN_OK;
 }
 #define SYNC_ALL(c) do { int rc_ = sync_all(c); if (rc_) return rc_; } while (0)
@@ -213,6 +226,7 @@ const char* ocean_strerror(int code)
         case OCEAN_E_NOT_READY: return "ocean_prepare has not been called";
         case OCEAN_E_NOMEM: return "out of memory";
         case OCEAN_E_UNSUPPORTED: return "tile size must be a power of two in [16, 4096]";
+        case OCEAN_E_COMM: return "RCCL error (or librccl could not be loaded); see ocean_last_rccl_error";
         default: return "unknown error";
     }
 }
@@ -261,6 +275,7 @@ void ocean_destroy(ocean_t* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    comm_release(c);
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->grid_pos) (void)hipFree(c->grid_pos);
@@ -414,9 +429,19 @@ static hipError_t allow_lds(K kernel, size_t bytes)
                                (int)bytes);
 }
 
+// One kernel launch.  With an event pair the launch goes through hipExtLaunchKernelGGL, which attaches the events
+// to the dispatch itself: their interval is the kernel's own execution time (what rocprofv3 reports), free of the
+// 2.5-3 us of marker/launch processing that events recorded around a launch carry.
+template <class K, class... A>
+static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t* ev, A... args)
+{
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, ev[0], ev[1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+
 template <int N>
 static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
-                               hipStream_t st, hipEvent_t* marks /* 4 events or null */)
+                               hipStream_t st, hipEvent_t* marks /* 6 events (start, stop per kernel) or null */)
 {
     using G = Geo<N>;
     using HF = Half<N>;
@@ -455,14 +480,13 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     };
     arm(0);
 #endif
-    if (marks) (void)hipEventRecord(marks[0], st);
     {
         unsigned gx = N / 2 + 1;
 #ifdef OCEAN_STAMPS
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
-#define OCEAN_ZPASS(h16, w16, znt) hipLaunchKernelGGL((k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt>), grid, block, lds_rows, st, a)
+#define OCEAN_ZPASS(h16, w16, znt) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt>, grid, block, lds_rows, st, marks, a)
         const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
         switch (variant) {
             case 0: OCEAN_ZPASS(false, false, false); break;
@@ -476,20 +500,17 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         }
 #undef OCEAN_ZPASS
     }
-    if (marks) (void)hipEventRecord(marks[1], st);
 #ifdef OCEAN_STAMPS
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
     arm(1);
 #endif
-    if (stream_maps & 1) hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, true>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
-    else hipLaunchKernelGGL((k_xpass_b<N, C, G::T_C, typename G::PC, false>), dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, a);
-    if (marks) (void)hipEventRecord(marks[2], st);
+    if (stream_maps & 1) launch(k_xpass_b<N, C, G::T_C, typename G::PC, true>, dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, marks ? marks + 2 : nullptr, a);
+    else launch(k_xpass_b<N, C, G::T_C, typename G::PC, false>, dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, marks ? marks + 2 : nullptr, a);
 #ifdef OCEAN_STAMPS
     arm(2);
 #endif
-    if (stream_maps & 2) hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, true>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
-    else hipLaunchKernelGGL((k_xpass_disp<N, C, G::T_C, typename G::PC, false>), dim3(nb, tiles), dim3(G::T_C), lds_m, st, a);
-    if (marks) (void)hipEventRecord(marks[3], st);
+    if (stream_maps & 2) launch(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, dim3(nb, tiles), dim3(G::T_C), lds_m, st, marks ? marks + 4 : nullptr, a);
+    else launch(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, dim3(nb, tiles), dim3(G::T_C), lds_m, st, marks ? marks + 4 : nullptr, a);
     return hipGetLastError();
 }
 
@@ -513,6 +534,10 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         if (rc_) return rc_;
     }
     hipStream_t st = stream_of(c, set);
+    if (c->gather_pending[set]) {        // this chain's maps are still being sent: the frame may not rewrite them yet
+        HIP_TRY(hipStreamWaitEvent(st, c->gather_done[set], 0));
+        c->gather_pending[set] = false;
+    }
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
     a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
@@ -681,6 +706,31 @@ int ocean_read_maps_async(ocean_t* c, uint32_t first, uint32_t count, float* dis
     hipStream_t st = stream_of(c, c->last_set);          // ordered after the frame that wrote these maps
     if (disp) HIP_TRY(hipMemcpyAsync(disp, d, count * n2 * sizeof(float4), hipMemcpyDeviceToHost, st));
     if (nrm) HIP_TRY(hipMemcpyAsync(nrm, q, count * n2 * sizeof(float4), hipMemcpyDeviceToHost, st));
+    return OCEAN_OK;
+}
+
+size_t ocean_staging_map_offset(size_t vertices_bytes, size_t indices_bytes)
+{
+    // AlignSizeTo(verticesSize + indicesSize, FormatToBytes(RGBA32F) = 16): WaterSurfaceMesh.cpp:19-22, 721-724
+    return (vertices_bytes + indices_bytes + 15u) & ~(size_t)15u;
+}
+
+int ocean_read_maps_staging(ocean_t* c, uint32_t tile, void* mapped_base, size_t vertices_bytes, size_t indices_bytes,
+                            size_t* bytes_to_flush)
+{
+    if (!c || tile >= c->tiles || !mapped_base) return OCEAN_E_INVALID;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t map_bytes = (size_t)c->n * c->n * sizeof(float4);
+    const size_t off = ocean_staging_map_offset(vertices_bytes, indices_bytes);
+    const float4* d = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + (size_t)tile * c->n * c->n;
+    const float4* q = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + (size_t)tile * c->n * c->n;
+    hipStream_t st = stream_of(c, c->last_set);           // ordered behind the frame that wrote these maps
+    char* base = static_cast<char*>(mapped_base);
+    // [vertices | indices | pad to 16 | displacements | normals]  (WaterSurfaceMesh.cpp:712-744)
+    HIP_TRY(hipMemcpyAsync(base + off, d, map_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(base + off + map_bytes, q, map_bytes, hipMemcpyDeviceToHost, st));
+    if (bytes_to_flush) *bytes_to_flush = off + 2 * map_bytes;      // the size the reference flushes from offset 0 (.cpp:746-753)
     return OCEAN_OK;
 }
 
@@ -869,10 +919,10 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
         double acc[3] = {0, 0, 0};
         long counted = 0;
         auto collect = [&](int set) -> int {
-            HIP_TRY(hipEventSynchronize(c->mark_ev[set][3]));
+            HIP_TRY(hipEventSynchronize(c->mark_ev[set][5]));
             for (int k = 0; k < 3; ++k) {
                 float m = 0.f;
-                HIP_TRY(hipEventElapsedTime(&m, c->mark_ev[set][k], c->mark_ev[set][k + 1]));
+                HIP_TRY(hipEventElapsedTime(&m, c->mark_ev[set][2 * k], c->mark_ev[set][2 * k + 1]));
                 acc[k] += m;
             }
             ++counted;
@@ -943,6 +993,131 @@ int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
     // in) + 2 + 2 (raw height) + 32 (maps).  SURVEY.md 8d's model of a plain 3.5-transform two-pass scheme is 108.
     if (!c) return 74;
     return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------
+// Packed-map gather over RCCL (the north-star's one exchange step).  Tiles are independent, so
+// synthesis needs no collective; the only communication is every rank sending its finished maps to a root.
+// librccl is loaded on first use (dlopen) so that single-GPU users of the library carry no dependency on it;
+// inside a PyTorch process the already-loaded librccl.so.1 is the one found.
+namespace {
+struct RcclApi {
+    void* so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", nullptr};
+        for (int i = 0; names[i] && !a.so; ++i) a.so = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!a.so) return a;
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.so, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.so, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.so, "ncclCommDestroy");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(a.so, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.so, "ncclGroupEnd");
+        a.Gather = (decltype(a.Gather))dlsym(a.so, "ncclGather");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Gather;
+        return a;
+    }();
+    return api;
+}
+thread_local int g_last_rccl = 0;
+}  // namespace
+#define RCCL_TRY(expr)                                  \
+    do {                                                \
+        ncclResult_t r_ = (expr);                       \
+        if (r_ != ncclSuccess) {                        \
+            g_last_rccl = (int)r_;                      \
+            return OCEAN_E_COMM;                        \
+        }                                               \
+    } while (0)
+
+static void comm_release(ocean_ctx* c)
+{
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    for (auto& e : c->frame_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : c->gather_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (bool& p : c->gather_pending) p = false;
+    c->comm_ranks = 0; c->comm_rank = -1;
+}
+
+extern "C" {
+
+int ocean_last_rccl_error(void) { return g_last_rccl; }
+
+int ocean_comm_unique_id(void* id_out)
+{
+    if (!id_out) return OCEAN_E_INVALID;
+    static_assert(sizeof(ncclUniqueId) == OCEAN_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!rccl().ok) return OCEAN_E_COMM;
+    ncclUniqueId id;
+    RCCL_TRY(rccl().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return OCEAN_OK;
+}
+
+int ocean_comm_init(ocean_t* c, int nranks, int rank, const void* id_in)
+{
+    if (!c || !id_in || nranks < 1 || rank < 0 || rank >= nranks) return OCEAN_E_INVALID;
+    if (!rccl().ok) return OCEAN_E_COMM;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    comm_release(c);
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof(id));
+    RCCL_TRY(rccl().CommInitRank(&c->comm, nranks, id, rank));      // collective: every rank of the job calls it
+    c->comm_ranks = nranks; c->comm_rank = rank;
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (auto& e : c->frame_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->gather_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return OCEAN_OK;
+}
+
+int ocean_comm_destroy(ocean_t* c)
+{
+    if (!c) return OCEAN_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    comm_release(c);
+    return OCEAN_OK;
+}
+
+int ocean_gather_maps(ocean_t* c, int root, void* d_recv_disp, void* d_recv_nrm)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (!c->comm) return OCEAN_E_NOT_READY;
+    if (root < 0 || root >= c->comm_ranks) return OCEAN_E_INVALID;
+    if (c->comm_rank == root && (!d_recv_disp || !d_recv_nrm)) return OCEAN_E_INVALID;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    const int set = c->last_set;
+    const size_t count = (size_t)c->tiles * c->n * c->n * 4;                 // floats per map array per rank
+    const float4* d = c->ext_disp ? c->ext_disp : c->dispN[set];
+    const float4* q = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
+    // order the gather behind the frame that wrote these maps, on the communication stream: the chains keep
+    // synthesising meanwhile (at depth >= 2 the next frames write other map sets), and this chain's next frame
+    // waits for gather_done before it rewrites the maps (enqueue_frame)
+    HIP_TRY(hipEventRecord(c->frame_done[set], stream_of(c, set)));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->frame_done[set], 0));
+    RCCL_TRY(rccl().GroupStart());
+    ncclResult_t r1 = rccl().Gather(d, d_recv_disp, count, ncclFloat, root, c->comm, c->comm_stream);   // zero-copy from the map buffers
+    ncclResult_t r2 = rccl().Gather(q, d_recv_nrm, count, ncclFloat, root, c->comm, c->comm_stream);
+    RCCL_TRY(rccl().GroupEnd());
+    RCCL_TRY(r1); RCCL_TRY(r2);
+    HIP_TRY(hipEventRecord(c->gather_done[set], c->comm_stream));
+    c->gather_pending[set] = true;
+    return OCEAN_OK;
 }
 
 }  // extern "C"

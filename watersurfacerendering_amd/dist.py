@@ -1,11 +1,16 @@
-"""Tile sharding across ranks (one process per GPU) and the packed-map gather.
+"""Tile sharding across ranks (one process per GPU) and the control plane of the packed-map gather.
 
 Tiles are independent (own seed / parameters / time), so a
 batch is partitioned with NO data-path collective during synthesis.  The only
 exchange step the north-star names is one gather of the finished packed maps
-to a root rank: `torch.distributed.gather` (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in the CPU tests).  Each peer has a direct xGMI link to the
-root, so the gather is world_size-1 concurrent point-to-point streams.
+to a root rank.  The DATA path of that gather is in the product library:
+`ocean_gather_maps` (include/ocean.h) = ncclGather x 2 on RCCL, zero-copy from
+the context's map buffers, world_size-1 concurrent point-to-point xGMI streams
+into the root.  This module holds what surrounds it on the host: the block
+partition of the tiles, the distribution of the RCCL unique id through whatever
+process group the harness already has (`exchange_unique_id`), the MAX-over-ranks
+timing reduction of the bench contract, and `gather_maps`, a torch.distributed
+gather of map tensors used by the CPU (gloo) tests of the rank-major layout.
 """
 from __future__ import annotations
 
@@ -51,6 +56,20 @@ def gather_maps(local_maps, dst: int = 0, group=None, async_op: bool = False):
         glist = [out[i] for i in range(world)]
     work = dist.gather(local_maps, gather_list=glist, dst=dst, group=group, async_op=async_op)
     return out, work
+
+
+def exchange_unique_id(W, src: int = 0, group=None) -> bytes:
+    """Rank `src` creates the RCCL unique id through the C ABI (ocean_comm_unique_id) and every rank of the
+    process group receives it (any backend: the id is 128 bytes of host data).  Single process: just creates it.
+    `W` is the watersurfacerendering_amd package (passed in so this module stays importable without the library)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return W.comm_unique_id()
+    box = [W.comm_unique_id() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    uid = box[0]
+    assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
+    return bytes(uid)
 
 
 def max_over_ranks(seconds: float, device: Optional[str] = None, group=None) -> float:
