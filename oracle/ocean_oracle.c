@@ -50,6 +50,7 @@
 #define ORACLE_FFT_F32 0        /* reference shape: float FFTs, one thread per 2-D transform */
 #define ORACLE_FFT_F64 1        /* float front end, FFT + pack in double              */
 #define ORACLE_FFT_F32_TEAM 2   /* float FFTs work-shared by every thread (not the reference's shape: the strong CPU baseline) */
+#define ORACLE_FFT_EXTERNAL 4    /* stage D done by a callback (a library FFT on every core): strong CPU baseline, not the reference's shape */
 #define ORACLE_FFT_FFTW 3       /* libfftw3f loaded at run time, the reference's plans (WSTessendorf.cpp:191-232); only if present */
 
 /* FFTW 3 (float) entry points, resolved with dlopen when the host has the library.  The reference links
@@ -77,6 +78,14 @@ int oracle_fftw_available(void)
 }
 
 int oracle_num_threads(void);
+typedef void (*oracle_fft_cb)(float* fields, int nfields, int n, void* user);
+#include <time.h>
+static double wall_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
 
 typedef struct oracle_ctx {
     /* properties: WSTessendorf.h:181-199 */
@@ -112,6 +121,9 @@ typedef struct oracle_ctx {
     cpx_d* work_d;
     cpx_f* work_team;        /* threads * 17n, ORACLE_FFT_F32_TEAM */
     void* fftw_plans[7];     /* ORACLE_FFT_FFTW: one in-place plan per field, like WSTessendorf.cpp:191-232 */
+    oracle_fft_cb ext_fft;   /* ORACLE_FFT_EXTERNAL */
+    void* ext_fft_user;
+    double stage_ms[4];      /* wall time of the last frame's stages: A-C spectra, D transforms, E-F pack, G normalise */
 } oracle_ctx;
 
 /* ------------------------------------------------------------------------ */
@@ -372,11 +384,10 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
             if (!c->fftw_plans[f]) c->fftw_plans[f] = g_fftw.plan((int)n, (int)n, c->ff + (size_t)f * n2, c->ff + (size_t)f * n2, +1, 0u);
     }
 
-    /* :289-290 -- max starts at numeric_limits<float>::min() (= FLT_MIN > 0) */
-    float master_max = FLT_MIN;
-    float master_min = FLT_MAX;
-    const float lambda = c->lambda;
-
+    const double t_begin = wall_ms();
+    /* One `omp parallel` region in the reference (.cpp:292-438); three here, split at the two points where the
+     * reference's team meets at a barrier anyway (before and after the transforms), so that stage D can also be
+     * handed to an external library FFT (ORACLE_FFT_EXTERNAL) without an idle team spinning beside it. */
     #pragma omp parallel
     {
         /* A :294-300, WaveHeightFT .h:265-275 */
@@ -411,27 +422,44 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
                 }
             }
         }
-        /* D :338-367 -- one single-threaded 2-D backward DFT per field */
-        if (fft_kind == ORACLE_FFT_F32) {
-            #pragma omp for schedule(dynamic, 1)
-            for (int f = 0; f < nfields; ++f)
-                fft2d_f(&c->pf, c->ff + (size_t)f * n2, c->work_f + (size_t)f * 17 * n);
-        } else if (fft_kind == ORACLE_FFT_F32_TEAM) {
-            fft2d_team_f(&c->pf, c->ff, nfields, c->work_team + (size_t)omp_get_thread_num() * 17 * n);
-        } else if (fft_kind == ORACLE_FFT_FFTW) {
-            #pragma omp for schedule(dynamic, 1)     /* omp sections of .cpp:338-367: one fftwf_execute per field */
-            for (int f = 0; f < nfields; ++f) g_fftw.exec(c->fftw_plans[f]);
-        } else {
-            #pragma omp for schedule(dynamic, 1)
-            for (int f = 0; f < nfields; ++f) {
-                cpx_d* dst = c->fd + (size_t)f * n2;
-                const cpx_f* src = c->ff + (size_t)f * n2;
-                for (size_t i = 0; i < n2; ++i) { dst[i].re = src[i].re; dst[i].im = src[i].im; }
-                fft2d_d(&c->pd, dst, c->work_d + (size_t)f * 17 * n);
-                cpx_f* back = c->ff + (size_t)f * n2;
-                for (size_t i = 0; i < n2; ++i) { back[i].re = (float)dst[i].re; back[i].im = (float)dst[i].im; }
+    }
+    const double t_spectra = wall_ms();
+    /* D :338-367 -- one single-threaded 2-D backward DFT per field */
+    if (fft_kind == ORACLE_FFT_EXTERNAL) {
+        if (!c->ext_fft) return NAN;
+        c->ext_fft((float*)c->ff, nfields, (int)n, c->ext_fft_user);     /* in place, unnormalised, backward */
+    } else {
+        #pragma omp parallel
+        {
+            if (fft_kind == ORACLE_FFT_F32) {
+                #pragma omp for schedule(dynamic, 1)
+                for (int f = 0; f < nfields; ++f)
+                    fft2d_f(&c->pf, c->ff + (size_t)f * n2, c->work_f + (size_t)f * 17 * n);
+            } else if (fft_kind == ORACLE_FFT_F32_TEAM) {
+                fft2d_team_f(&c->pf, c->ff, nfields, c->work_team + (size_t)omp_get_thread_num() * 17 * n);
+            } else if (fft_kind == ORACLE_FFT_FFTW) {
+                #pragma omp for schedule(dynamic, 1)     /* omp sections of .cpp:338-367: one fftwf_execute per field */
+                for (int f = 0; f < nfields; ++f) g_fftw.exec(c->fftw_plans[f]);
+            } else {
+                #pragma omp for schedule(dynamic, 1)
+                for (int f = 0; f < nfields; ++f) {
+                    cpx_d* dst = c->fd + (size_t)f * n2;
+                    const cpx_f* src = c->ff + (size_t)f * n2;
+                    for (size_t i = 0; i < n2; ++i) { dst[i].re = src[i].re; dst[i].im = src[i].im; }
+                    fft2d_d(&c->pd, dst, c->work_d + (size_t)f * 17 * n);
+                    cpx_f* back = c->ff + (size_t)f * n2;
+                    for (size_t i = 0; i < n2; ++i) { back[i].re = (float)dst[i].re; back[i].im = (float)dst[i].im; }
+                }
             }
         }
+    }
+    const double t_fft = wall_ms();
+    /* :289-290 -- max starts at numeric_limits<float>::min() (= FLT_MIN > 0) */
+    float master_max = FLT_MIN;
+    float master_min = FLT_MAX;
+    const float lambda = c->lambda;
+    #pragma omp parallel
+    {
         /* E :380-412 */
         float tmax = FLT_MIN, tmin = FLT_MAX;
         #pragma omp for schedule(static) nowait
@@ -468,14 +496,32 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
                 o[3] = nfields == 7 ? (float)sgn * dzd_z[i].re : 0.0f;
             }
     }
+    const double t_pack = wall_ms();
     /* G NormalizeHeights :443-455 -- serial in the reference */
     c->min_height = master_min;
     c->max_height = master_max;
     const float amp = fmaxf(fabsf(master_min), fabsf(master_max));
     const float inv = 1.f / amp;
-    for (size_t i = 0; i < n2; ++i) c->disp[4 * i + 1] *= inv;
+    if (fft_kind == ORACLE_FFT_F32_TEAM || fft_kind == ORACLE_FFT_EXTERNAL) {     /* the strong baselines also share this loop out (the reference's is serial) */
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n2; ++i) c->disp[4 * i + 1] *= inv;
+    } else {
+        for (size_t i = 0; i < n2; ++i) c->disp[4 * i + 1] *= inv;
+    }
+    const double t_end = wall_ms();
+    c->stage_ms[0] = t_spectra - t_begin; c->stage_ms[1] = t_fft - t_spectra;
+    c->stage_ms[2] = t_pack - t_fft; c->stage_ms[3] = t_end - t_pack;
     return amp;
 }
+
+/* Stage D through a caller-supplied transform (bench.py's cpu_baseline_strong hands it scipy's pocketfft on every
+ * core): cb(fields, nfields, n, user) must replace each of the nfields consecutive n x n complex-float arrays by
+ * its unnormalised backward 2-D DFT, in place. */
+void oracle_set_external_fft(oracle_ctx* c, oracle_fft_cb cb, void* user) { c->ext_fft = cb; c->ext_fft_user = user; }
+
+/* Wall time (ms) of the stages of the last oracle_compute_waves: [0] spectra A-C, [1] transforms D, [2] pack E-F,
+ * [3] normalise G (bench.py reports the split beside the CPU baseline). */
+const double* oracle_stage_ms(const oracle_ctx* c) { return c->stage_ms; }
 
 /* Raw (un-normalised, un-signed) complex FFT outputs of the last call, for
  * intermediate checks: field f in [0,7): h, sx, sz, Dx, Dz, dxDx, dzDz.     */

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libocean_oracle.so")
 
 MODE_FULL7, MODE_CHOPPY5, MODE_HEIGHT1 = 0, 1, 2
-FFT_F32, FFT_F64, FFT_F32_TEAM, FFT_FFTW = 0, 1, 2, 3     # see ocean_oracle.c
+FFT_F32, FFT_F64, FFT_F32_TEAM, FFT_FFTW, FFT_EXTERNAL = 0, 1, 2, 3, 4     # see ocean_oracle.c
 
 
 def build(force: bool = False) -> str:
@@ -35,6 +35,7 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+FFT_CB = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p)
 
 
 def lib() -> C.CDLL:
@@ -71,6 +72,10 @@ def lib() -> C.CDLL:
         L.oracle_gauss_pair.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_fftw_available.restype = C.c_int
+        L.oracle_set_external_fft.argtypes = [P, FFT_CB, C.c_void_p]
+        L.oracle_set_external_fft.restype = None
+        L.oracle_stage_ms.argtypes = [P]
+        L.oracle_stage_ms.restype = C.POINTER(C.c_double)
         L.oracle_fft2d_f32.argtypes = [C.c_int, C.c_void_p]
         L.oracle_fft2d_f64.argtypes = [C.c_int, C.c_void_p]
         _lib = L
@@ -132,6 +137,26 @@ class Oracle:
     min_height = property(lambda s: s._L.oracle_min_height(s._h))
     max_height = property(lambda s: s._L.oracle_max_height(s._h))
     base_freq = property(lambda s: s._L.oracle_base_freq(s._h))
+
+    def use_pocketfft(self, workers: int | None = None):
+        """Stage D of fft=FFT_EXTERNAL frames: scipy's pocketfft (complex64, in place) on `workers` threads."""
+        import scipy.fft
+        workers = workers or os.cpu_count()
+
+        def cb(ptr, nfields, n, _user):
+            a = np.ctypeslib.as_array(ptr, shape=(nfields, n, n, 2)).view(np.complex64)[..., 0]
+            out = scipy.fft.ifft2(a, axes=(1, 2), norm="forward", workers=workers, overwrite_x=True)
+            if out.ctypes.data != a.ctypes.data:
+                a[...] = out
+
+        self._fft_cb = FFT_CB(cb)            # keep the trampoline alive
+        self._L.oracle_set_external_fft(self._h, self._fft_cb, None)
+
+    @property
+    def stage_ms(self):
+        """Wall time of the last frame's stages: spectra (A-C), transforms (D), pack (E-F), normalise (G)."""
+        p = self._L.oracle_stage_ms(self._h)
+        return dict(spectra=p[0], transforms=p[1], pack=p[2], normalise=p[3])
 
     @property
     def wind(self):
