@@ -186,6 +186,14 @@ int ocean_set_dispersion(ocean_t* ctx, int kind, float param);
  * next ocean_prepare.  Accuracy: tests/test_parity_gpu.py states the measured bound.   */
 int ocean_set_spectrum_precision(ocean_t* ctx, int bits);
 
+/* Precision of the intermediates between the two passes: 32 (default) or 16.  With 16 the z-axis pass stores its
+ * outputs as half2, scaled per tile by a power of two chosen at ocean_prepare from a time-independent bound of the
+ * spectrum's column sums (nothing can overflow), and the x-axis pass reads them back: 7 instead of 14 bytes per
+ * texel each way (60 instead of 74 per frame).  This is BASELINE.json config 4's reduced-precision mode: the
+ * maps then differ from the fp32 path by up to ~1e-3 of a channel's maximum (tests state the measured bound);
+ * the default fp32 path keeps its 1e-5.  Takes effect at the next ocean_prepare.                                  */
+int ocean_set_intermediate_precision(ocean_t* ctx, int bits);
+
 /* Frame pipelining.  With depth D consecutive asynchronous frames rotate over D
  * independent chains (own stream, own intermediates, own internal map set): the
  * first pass of one frame fills the memory-idle phases of the other frames' map

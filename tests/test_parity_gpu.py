@@ -575,3 +575,51 @@ def test_random_call_sequences_match_oracle(seed):
                 m = float(np.abs(ref).max())
                 assert float(np.abs(got - ref).max()) <= TOL * max(m, 1e-30) or (m == 0.0 and np.all(got == 0.0)), (log, c)
     b.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 4's reduced mode: half2 intermediates between the two passes
+Z16_TOL = 1e-3       # stated tolerance: max|err| <= 1e-3 * max|channel| against the float64-FFT oracle (measured ~2e-4)
+
+
+@pytest.mark.parametrize("n,params", [(64, {}), (512, {}), (512, ALT), (2048, {}), (4096, {})])
+def test_fp16_intermediates_within_stated_tolerance(n, params):
+    """ocean_set_intermediate_precision(16): the z-pass outputs travel as scaled half2.  Within 1e-3 of every
+    channel's maximum at several times (the scale is time independent: nothing may overflow at any t), really
+    reduced precision, and the fp32 mode is untouched by the switch."""
+    from oracle import oracle as O
+    import watersurfacerendering_amd as W
+    seed = 0x5EED0000
+    kw = dict(params)
+    b = make_gpu(n, None, seed=seed, **kw)
+    xi = b.read_xi(0)
+    o = make_oracle(n, xi, **kw)
+    b.set_intermediate_precision(16)
+    with pytest.raises(W.OceanError):
+        b.compute_waves(0.0)            # needs Prepare(), like every spectrum parameter
+    b.prepare(seed)
+    assert b.algorithmic_bytes_per_texel == 60
+    worst = 0.0
+    for t in ((0.0, 4.5, 1000.0) if n <= 2048 else (4.5,)):
+        ao, do, no = o.compute_waves(t, fft=O.FFT_F64)
+        a16 = float(b.compute_waves(t)[0])
+        d16, n16 = b.read_maps()
+        assert np.all(np.isfinite(d16)) and np.all(np.isfinite(n16))
+        e16 = max(chan_err(d16[0], do)[:3] + chan_err(n16[0], no))
+        assert abs(a16 - ao) <= Z16_TOL * ao
+        assert e16 <= Z16_TOL, (t, e16)
+        worst = max(worst, e16)
+    assert worst > TOL / 10             # it really is the reduced-precision path
+    # pipelined frames in that mode equal serial ones bit for bit
+    b.compute_waves(2.0); d1, q1 = b.read_maps()
+    b.set_pipeline_depth(2)
+    for t in (0.5, 1.0, 2.0):
+        b.compute_waves_async(t)
+    b.synchronize(); d2, q2 = b.read_maps()
+    assert np.array_equal(d1, d2) and np.array_equal(q1, q2)
+    b.set_pipeline_depth(1)
+    b.set_intermediate_precision(32)
+    b.prepare(seed)
+    assert b.algorithmic_bytes_per_texel == 74
+    check_frame(b, o, 4.5)
+    b.close()

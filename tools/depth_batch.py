@@ -6,6 +6,7 @@ out = []
 for depth in depths:
     b = W.OceanBatch(n, tiles, 0)
     if os.environ.get('OCEAN_FP16'): b.set_spectrum_precision(16)
+    if os.environ.get('OCEAN_Z16'): b.set_intermediate_precision(16)
     if os.environ.get('OCEAN_MODE'): b.set_mode(int(os.environ['OCEAN_MODE']))
     b.prepare(1); b.set_pipeline_depth(depth)
     frames = int(os.environ.get("OCEAN_FRAMES", "1000"))

@@ -198,6 +198,10 @@ class OceanBatch:
     def set_spectrum_precision(self, bits: int):
         _abi.check(self._L.ocean_set_spectrum_precision(self._h, bits), "ocean_set_spectrum_precision")
 
+    def set_intermediate_precision(self, bits: int):
+        """32 (default) or 16: half2 intermediates between the two passes (config 4's reduced mode); next prepare()."""
+        _abi.check(self._L.ocean_set_intermediate_precision(self._h, bits), "ocean_set_intermediate_precision")
+
     def set_pipeline_depth(self, depth: int):
         _abi.check(self._L.ocean_set_pipeline_depth(self._h, depth), "ocean_set_pipeline_depth")
 

@@ -37,7 +37,7 @@ SYMBOLS = [
     "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_bind_output",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_gather_maps", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_read_grid", "ocean_device_grid",
-    "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
+    "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
     "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
 ]
 
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
         "ocean_set_mode": (i32, [P, i32]),
         "ocean_set_dispersion": (i32, [P, i32, f32]),
         "ocean_set_spectrum_precision": (i32, [P, i32]),
+        "ocean_set_intermediate_precision": (i32, [P, i32]),
         "ocean_set_pipeline_depth": (i32, [P, i32]),
         "ocean_stream": (P, [P]),
         "ocean_set_stream": (i32, [P, P]),

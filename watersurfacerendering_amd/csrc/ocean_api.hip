@@ -79,6 +79,10 @@ struct ocean_ctx {
     TileParams* tparams = nullptr;
     float2* xi = nullptr;          // injected or generated draws (kept for read-back)
     int mode = 0;                  // OCEAN_MODE_*
+    int inter_bits_zeroed = 32;    // layout the intermediates' padding was last zero-filled for
+    int inter_bits = 32;           // 32, or 16: the z-pass outputs (z, zh) are stored as scaled half2 (ocean_set_intermediate_precision)
+    float4* zscale = nullptr;      // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k)
+    unsigned* zbounds = nullptr;   // [tiles][2] float bits of the column-sum bounds (k_inter_bounds)
     int h0_bits = 32;              // 32, or 16: frames read a scaled half2 copy of h0
     __half2* h0h = nullptr;
     float* h0_inv_scale = nullptr;
@@ -107,13 +111,13 @@ static hipStream_t stream_of(const ocean_ctx* c, int set);
 static void free_device(ocean_ctx* c)
 {
     void* bufs[] = {c->h0, c->omega, c->omega_q, c->base_freq, c->omega_q_overflow, c->k1d, c->tw, c->toff, c->lambda, c->tparams, c->xi,
-                    c->h0h, c->h0_inv_scale, c->h0_maxbits};
+                    c->h0h, c->h0_inv_scale, c->h0_maxbits, c->zscale, c->zbounds};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < MAXD; ++i) free_set(c, i);
     c->h0 = nullptr; c->omega = nullptr; c->omega_q = nullptr; c->base_freq = nullptr; c->omega_q_overflow = nullptr;
     c->k1d = nullptr; c->tw = nullptr;
     c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
-    c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr;
+    c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr; c->zscale = nullptr; c->zbounds = nullptr;
     c->prepared = false;
 }
 
@@ -394,6 +398,45 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
                            c->h0_inv_scale, n2);
         HIP_TRY(hipGetLastError());
     }
+    if (c->inter_bits != c->inter_bits_zeroed) {
+        // the two precisions lay the same elements out at 8 or 4 bytes each: what one wrote sits in the other's
+        // padding columns, which must read as zero -> zero-fill every allocated chain again
+        const size_t nu = n / 2 + 1, nup = n / 2 + 8;
+        SYNC_ALL(c);
+        for (int i = 0; i < MAXD; ++i)
+            if (c->z[i]) {
+                HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
+                HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
+            }
+        c->inter_bits_zeroed = c->inter_bits;
+    }
+    if (c->inter_bits == 16) {
+        if (!c->zscale) {
+            HIP_TRY(hipMalloc(&c->zscale, t * sizeof(float4)));
+            HIP_TRY(hipMalloc(&c->zbounds, t * 2 * sizeof(unsigned)));
+        }
+        HIP_TRY(hipMemsetAsync(c->zbounds, 0, t * 2 * sizeof(unsigned), stream_of(c, 0)));
+        hipLaunchKernelGGL(k_inter_bounds, dim3((unsigned)n, (unsigned)t), dim3(256), 0, stream_of(c, 0), c->h0, c->k1d, c->zbounds, (int)n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream_of(c, 0)));
+        std::vector<unsigned> hb(2 * t);
+        HIP_TRY(hipMemcpy(hb.data(), c->zbounds, 2 * t * sizeof(unsigned), hipMemcpyDeviceToHost));
+        std::vector<float4> zs(t);
+        for (size_t i = 0; i < t; ++i) {
+            float sc[2];
+            for (int k = 0; k < 2; ++k) {
+                float b; std::memcpy(&b, &hb[2 * i + k], 4);
+                // a component of a z-pass output is bounded by 2 * (column sum + mirrored column sum) <= 4 * max column
+                // sum; the largest finite half is 65504: scale = the largest power of two with 4 * b * scale <= 32768
+                const float bound = 4.0f * b;
+                int e = 0;
+                if (bound > 0.0f && std::isfinite(bound)) (void)std::frexp(bound, &e);     // bound = f * 2^e, f in [0.5, 1)
+                sc[k] = bound > 0.0f ? std::ldexp(1.0f, 15 - e) : 1.0f;
+            }
+            zs[i] = make_float4(sc[0], sc[1], 1.0f / sc[0], 1.0f / sc[1]);
+        }
+        HIP_TRY(hipMemcpy(c->zscale, zs.data(), t * sizeof(float4), hipMemcpyHostToDevice));
+    }
     SYNC_ALL(c);
     {
         unsigned overflow = 1;
@@ -456,18 +499,19 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     if (c->attr_n != (uint32_t)N) {
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, false>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, false>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, false>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true, false>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, true>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, true>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, true>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true, true>, lds_rows)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, lds_m)) != hipSuccess) return e;
+#define OCEAN_ALLOW_Z(h16, w16, znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, lds_rows)) != hipSuccess) return e;
+#define OCEAN_ALLOW_Z4(h16, w16) OCEAN_ALLOW_Z(h16, w16, false, false) OCEAN_ALLOW_Z(h16, w16, true, false) OCEAN_ALLOW_Z(h16, w16, false, true) OCEAN_ALLOW_Z(h16, w16, true, true)
+        OCEAN_ALLOW_Z4(false, false) OCEAN_ALLOW_Z4(true, false) OCEAN_ALLOW_Z4(false, true) OCEAN_ALLOW_Z4(true, true)
+#undef OCEAN_ALLOW_Z4
+#undef OCEAN_ALLOW_Z
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, false>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, false>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, true>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, true>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, false>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, false>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, true>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, true>, lds_m)) != hipSuccess) return e;
         c->attr_n = (uint32_t)N;
     }
 #ifdef OCEAN_STAMPS
@@ -486,7 +530,9 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
-#define OCEAN_ZPASS(h16, w16, znt) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt>, grid, block, lds_rows, st, marks, a)
+#define OCEAN_ZPASS(h16, w16, znt) \
+        do { if (stream_maps & 8) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, true>, grid, block, lds_rows, st, marks, a); \
+             else launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, false>, grid, block, lds_rows, st, marks, a); } while (0)
         const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
         switch (variant) {
             case 0: OCEAN_ZPASS(false, false, false); break;
@@ -504,13 +550,22 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
     arm(1);
 #endif
-    if (stream_maps & 1) launch(k_xpass_b<N, C, G::T_C, typename G::PC, true>, dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, marks ? marks + 2 : nullptr, a);
-    else launch(k_xpass_b<N, C, G::T_C, typename G::PC, false>, dim3(hb_b + nb, tiles), dim3(G::T_C), lds_b, st, marks ? marks + 2 : nullptr, a);
+    {
+        const dim3 gb(hb_b + nb, tiles), gd(nb, tiles), blk(G::T_C);
+        hipEvent_t* mb = marks ? marks + 2 : nullptr;
+        hipEvent_t* md = marks ? marks + 4 : nullptr;
+#define OCEAN_XPASS(kern, grid, lds, ev, nts)                                                                       \
+        do { if (stream_maps & 8) launch(kern<N, C, G::T_C, typename G::PC, nts, true>, grid, blk, lds, st, ev, a);    \
+             else launch(kern<N, C, G::T_C, typename G::PC, nts, false>, grid, blk, lds, st, ev, a); } while (0)
+        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true);
+        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false);
 #ifdef OCEAN_STAMPS
-    arm(2);
+        arm(2);
 #endif
-    if (stream_maps & 2) launch(k_xpass_disp<N, C, G::T_C, typename G::PC, true>, dim3(nb, tiles), dim3(G::T_C), lds_m, st, marks ? marks + 4 : nullptr, a);
-    else launch(k_xpass_disp<N, C, G::T_C, typename G::PC, false>, dim3(nb, tiles), dim3(G::T_C), lds_m, st, marks ? marks + 4 : nullptr, a);
+        if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true);
+        else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false);
+#undef OCEAN_XPASS
+    }
     return hipGetLastError();
 }
 
@@ -542,6 +597,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
     a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
+    a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.minmax_host = c->mm_host[set];
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
@@ -568,14 +624,15 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.mode = c->mode;
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
     int stream_maps = (c->n >= 4096 || pipe) ? 3 : 0;
+    if (c->inter_bits == 16) stream_maps |= 8;          // bit 3: half2 intermediates (kernel variant, not a store policy)
     {   // what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the
         // 256 MiB memory-side cache: beyond it the intermediates are streamed too (bit 2, see store_z)
         const double texels = (double)c->tiles * (double)c->n * (double)c->n;
-        const double resident = texels * (10.0 + 16.0 * (pipe ? c->depth : 1));
+        const double resident = texels * (10.0 + (c->inter_bits == 16 ? 8.0 : 16.0) * (pipe ? c->depth : 1));
         if (resident > 300.0e6) stream_maps |= 4;
     }
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs): bit mask
-    if (stream_env) stream_maps = atoi(stream_env);
+    if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 8);
     hipError_t e = hipErrorInvalidValue;
     switch (c->n) {
         case 16: e = launch_frame<16>(c, a, stream_maps, st, marks); break;
@@ -875,6 +932,14 @@ int ocean_set_spectrum_precision(ocean_t* c, int bits)
     return OCEAN_OK;
 }
 
+int ocean_set_intermediate_precision(ocean_t* c, int bits)
+{
+    if (!c || (bits != 16 && bits != 32)) return OCEAN_E_INVALID;
+    if (bits != c->inter_bits) c->prepared = false;   // the scales are chosen by ocean_prepare
+    c->inter_bits = bits;
+    return OCEAN_OK;
+}
+
 int ocean_set_pipeline_depth(ocean_t* c, int depth)
 {
     if (!c || depth < 1 || depth > MAXD) return OCEAN_E_INVALID;
@@ -992,7 +1057,7 @@ int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
     // 8 (h0) + 2 (16-bit dispersion; 4 when the fp32 array is needed) + 14 + 14 (half-size intermediates out and
     // in) + 2 + 2 (raw height) + 32 (maps).  SURVEY.md 8d's model of a plain 3.5-transform two-pass scheme is 108.
     if (!c) return 74;
-    return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0);
+    return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0) - (c->inter_bits == 16 ? 14 : 0);
 }
 
 }  // extern "C"

@@ -80,14 +80,38 @@ template <class T> __device__ __forceinline__ const T& at32(const T* base, unsig
 // cache (4096^2, or large batches of tiles with several frames in flight): written non-temporally they
 // at least leave the cache to the spectrum, which is re-read every frame (4096^2: -4 %, 8 x 1024^2 at
 // depth 2: -5 %); where they do fit, a plain store keeps them on chip for the x pass (2048^2: 54 vs 60 us).
-template <bool ZNT> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v)
+// Z16 = reduced-precision intermediates (ocean_set_intermediate_precision(16)): the z-pass outputs are stored as
+// half2, multiplied first by a per-tile power of two `scale` chosen at ocean_prepare from a time-independent bound
+// of the column sums so that nothing can overflow (k_inter_bounds); the same arrays, half the bytes (14 -> 7 B/texel
+// out of the z pass and into the x pass).  Stated accuracy of that mode: tests/test_parity_gpu.py.
+template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v, float scale = 1.0f)
 {
-    if constexpr (ZNT) {
+    if constexpr (Z16) {
+        const __half2 h = __floats2half2_rn(v.x * scale, v.y * scale);
+        unsigned bits;
+        __builtin_memcpy(&bits, &h, 4);
+        unsigned* p = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(base) + idx * 4u);
+        if constexpr (ZNT) __builtin_nontemporal_store(bits, p);
+        else *p = bits;
+    } else if constexpr (ZNT) {
         typedef float f2nt __attribute__((ext_vector_type(2)));
         const f2nt t = {v.x, v.y};
         __builtin_nontemporal_store(t, reinterpret_cast<f2nt*>(reinterpret_cast<char*>(base) + idx * 8u));
     } else {
         *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+    }
+}
+// element idx of an intermediate array as float2 (times `unscale` in the half2 form)
+template <bool Z16> __device__ __forceinline__ float2 load_z(const float2* base, unsigned idx, float unscale)
+{
+    if constexpr (Z16) {
+        const unsigned bits = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(base) + idx * 4u);
+        __half2 h;
+        __builtin_memcpy(&h, &bits, 4);
+        const float2 f = __half22float2(h);
+        return make_float2(f.x * unscale, f.y * unscale);
+    } else {
+        return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + idx * 8u);
     }
 }
 template <class T> __device__ __forceinline__ T& at32(T* base, unsigned idx)
@@ -120,6 +144,7 @@ struct FrameArgs {
     float2* z;               // [tiles][3][N/2+1][2][NUP] row-transformed pairs: row m, side 0 = columns
                              //   u = 0..N/2, side 1 = columns (N-u)%N, NUP = N/2 + 8 (padded)
     float2* zh;              // [tiles][N/2+1][NUP]      row-transformed height, columns 0..N/2
+    const float4* zscale;    // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k): powers of two of the half2 intermediates (Z16 kernels)
     float* hraw;             // [tiles][NUP][N]          signed raw height of map rows 0..N/2 (+ padding rows)
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
     unsigned* minmax_host;   // [tiles][2]       host-coherent copy, written by the displacement pass
@@ -277,6 +302,37 @@ __global__ void k_h0_to_half(const float2* __restrict__ h0, __half2* __restrict_
     }
 }
 
+// Bounds for the half2 intermediates (ocean_set_intermediate_precision(16)), per tile, time independent:
+//   |h~(k, t)| <= 2 |h0(k)|, so every component of a z-pass output of spectrum column n is at most
+//   2 * sum_e |h0(e, n)| + 2 * sum_e |h0(e, -n)|   for the fields weighted by unit vectors (pair 0, height), and the same
+//   with |k| |h0| for the fields weighted by k (pairs 1 and 2).  One workgroup per spectrum column (contiguous in the
+//   transposed layout) sums |h0| and |k| |h0|; the maxima over the columns go to bounds[tile][0..1] as float bits.
+__global__ void k_inter_bounds(const float2* __restrict__ h0, const float* __restrict__ k1d, unsigned* __restrict__ bounds, int n)
+{
+    const int tile = blockIdx.y, col = blockIdx.x;
+    const float2* __restrict__ c = h0 + ((size_t)tile * n + col) * n;
+    const float* __restrict__ k1 = k1d + (size_t)tile * n;
+    const float kx = k1[col];
+    float su = 0.0f, sk = 0.0f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const float2 v = c[e];
+        const float m = sqrtf(v.x * v.x + v.y * v.y), kz = k1[e];
+        su += m;
+        sk += m * sqrtf(kx * kx + kz * kz);
+    }
+    __shared__ float ru[16], rk[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { su += __shfl_xor(su, o); sk += __shfl_xor(sk, o); }
+    if ((threadIdx.x & 63) == 0) { ru[threadIdx.x >> 6] = su; rk[threadIdx.x >> 6] = sk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tu = 0.0f, tk = 0.0f;
+        for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) { tu += ru[w]; tk += rk[w]; }
+        atomicMax(bounds + 2 * tile + 0, __float_as_uint(tu));      // non-negative floats order like uints
+        atomicMax(bounds + 2 * tile + 1, __float_as_uint(tk));
+    }
+}
+
 // ============================================================================
 // h~(k, t): WaveHeightFT (.h:265-275).  conj(h0(-k)) of the reference equals
 // conj(h0(k)) (same gaussian draw, Phillips even in k: .cpp:131-135), so
@@ -360,15 +416,19 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
 
 // The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
 // column nb == 0, the only one where Tx = S- along the whole column.
-template <int N, int T, class P, bool COL0, bool ZNT>
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
                                                  const TwiddleRegs<N, 2, T, P>& twr, float kx, float sm0, int tid,
                                                  int tile, int nb)
 {
     using HF = Half<N>;
     const float kx2 = kx * kx;
-    float2* __restrict__ zt = a.z + (size_t)tile * HF::Z_TILE + (size_t)nb * 2 * HF::NUP;
-    float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE + (size_t)nb * HF::NUP;
+    [[maybe_unused]] float su = 1.0f, sk = 1.0f;              // half2 intermediates: pair 0 and the height scale with su, pairs 1 and 2 with sk
+    if constexpr (Z16) { const float4 zs = a.zscale[tile]; su = zs.x; sk = zs.y; }
+    // element offsets; the half2 form packs the same elements at 4 bytes each from the same base address
+    constexpr size_t ES = Z16 ? 4 : 8;
+    float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + ((size_t)tile * HF::Z_TILE + (size_t)nb * 2 * HF::NUP) * ES);
+    float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + ((size_t)tile * HF::ZH_TILE + (size_t)nb * HF::NUP) * ES);
     // S+(e) and Tx(e), Tz(e)
     auto fetch = [&](int e, float& sv, float& tx, float& tz) {
         if constexpr (COL0) {
@@ -402,7 +462,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #endif
             // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored
             // positions 0 and N/2 exist on side 0 only: the x pass knows)
-            store_z<ZNT>(zt, (unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v);
+            store_z<ZNT, Z16>(zt, (unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, c ? sk : su);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -428,10 +488,10 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (p <= N / 2) store_z<ZNT>(zh, (unsigned)p, v);     // real input: other half is the conjugate
+                if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);     // real input: other half is the conjugate
                 return;
             }
-            store_z<ZNT>(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v);
+            store_z<ZNT, Z16>(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, sk);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -456,7 +516,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
 // 1024 and 4096 would spill at that cap and keep the looser one
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
-template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false>
+template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false, bool Z16 = false>
 __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -553,8 +613,8 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     __syncthreads();
     OCEAN_STAMP(1);
 
-    if (col0) zpass_transforms<N, T, P, true, ZNT>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
-    else zpass_transforms<N, T, P, false, ZNT>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_transforms<N, T, P, false, ZNT, Z16>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
 }
 
 template <int N> constexpr size_t zpass_lds_bytes()
@@ -565,17 +625,18 @@ template <int N> constexpr size_t zpass_lds_bytes()
 // ---- x-pass helpers ------------------------------------------------------------------
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the
 // mirror image eps * Z(N-mf, N-u) = eps * side 1 of row N-mf.
-template <int N>
-__device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, int mf, int u, float eps)
+template <int N, bool Z16 = false>
+__device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, int mf, int u, float eps, float unscale = 1.0f)
 {
     using HF = Half<N>;
 #ifdef OCEAN_ABL_NOLOAD
     return make_float2(1.0f + mf, 0.5f * u);
 #endif
-    if (mf <= N / 2) return at32(zg, (unsigned)(mf * 2 * HF::NUP + u));
+    if (mf <= N / 2) return load_z<Z16>(zg, (unsigned)(mf * 2 * HF::NUP + u), unscale);
     // mirror of the self-mirrored units 0 and N/2 is the unit itself (side 0)
     const int side = (u == 0 || u == N / 2) ? 0 : 1;
-    const c32 v = at32(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u));
+    if constexpr (Z16) return load_z<true>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), eps * unscale);
+    const c32 v = load_z<false>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), 1.0f);
     return make_float2(eps * v.x, eps * v.y);
 }
 
@@ -608,7 +669,7 @@ __device__ __forceinline__ void for_each_output(int tid, F f)
 // one height launch, then all three pairs per workgroup with register prefetch -- was
 // measured slower at every size and removed.)
 // ============================================================================
-template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false>
 __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -627,12 +688,23 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         constexpr int NW = (T + 63) / 64;
         float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
         const int u0 = xcd_swizzle(blockIdx.x, HB) * 2 * C;
-        const float2* __restrict__ zh = a.zh + (size_t)tile * HF::ZH_TILE;
+        constexpr size_t ES = Z16 ? 4 : 8;
+        const float2* __restrict__ zh = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
         float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
         float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
+        [[maybe_unused]] const float uu = Z16 ? a.zscale[tile].z : 1.0f;
         auto in = [&](int nf, int c, int, int) -> c32 {
             const int row = nf <= N / 2 ? nf : N - nf;
-            const float4 z = *reinterpret_cast<const float4*>(&at32(zh, (unsigned)(row * HF::NUP + u0 + 2 * c)));
+            float4 z;
+            if constexpr (Z16) {      // two half2 units in one 8-byte load
+                const float2 raw2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(zh) + (unsigned)(row * HF::NUP + u0 + 2 * c) * 4u);
+                __half2 ha, hb;
+                __builtin_memcpy(&ha, &raw2.x, 4); __builtin_memcpy(&hb, &raw2.y, 4);
+                const float2 fa = __half22float2(ha), fb = __half22float2(hb);
+                z = make_float4(fa.x * uu, fa.y * uu, fb.x * uu, fb.y * uu);
+            } else {
+                z = *reinterpret_cast<const float4*>(&at32(zh, (unsigned)(row * HF::NUP + u0 + 2 * c)));
+            }
             if (nf == 0 || nf == N / 2) return make_float2(z.x, z.z);
             if (nf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
             return make_float2(z.x + z.w, z.z - z.y);
@@ -667,8 +739,10 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     // between the transforms -- was measured 50% slower: the partial lines do not meet in L2)
     using LS = LastStage<N, C, T, P, LM>;
     const int u0 = xcd_swizzle(blockIdx.x - HB, NB) * C;
-    const float2* __restrict__ z1 = a.z + (size_t)tile * HF::Z_TILE + HF::Z_GROUP;
-    const float2* __restrict__ z2 = z1 + HF::Z_GROUP;
+    constexpr size_t ESN = Z16 ? 4 : 8;
+    const float2* __restrict__ z1 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + ((size_t)tile * HF::Z_TILE + HF::Z_GROUP) * ESN);
+    const float2* __restrict__ z2 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(z1) + HF::Z_GROUP * ESN);
+    [[maybe_unused]] const float uk = Z16 ? a.zscale[tile].w : 1.0f;
     float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
     c32 held[LS::IT][LS::RL];
     auto emit = [&](int p, int c, c32 slopes, c32 derivs) {
@@ -700,7 +774,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             if (!FS::GUARD || w < FS::ITEMS) {
                 const int c = w % C, j = w / C;
 #pragma unroll
-                for (int i = 0; i < FS::R0; ++i) dst[u][i] = load_pair_column<N>(zg, j + i * FS::STRIDE, u0 + c, eps);
+                for (int i = 0; i < FS::R0; ++i) dst[u][i] = load_pair_column<N, Z16>(zg, j + i * FS::STRIDE, u0 + c, eps, uk);
             }
         }
     };
@@ -712,7 +786,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     } else {
-        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z1, nf, u0 + c, -1.0f); };
+        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z1, nf, u0 + c, -1.0f, uk); };
         auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
@@ -728,13 +802,13 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         // keep the second transform's loads from being hoisted over the first one's last
         // stage: that costs ~45 VGPRs and with them the second workgroup per CU
         __builtin_amdgcn_sched_barrier(0);
-        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z2, nf, u0 + c, 1.0f); };
+        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z2, nf, u0 + c, 1.0f, uk); };
         auto out = [&](int p, int c, c32 v, int u, int i) { emit(p, c, held[u][i], v); };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
 }
 
-template <int N, int C, int T, class P = Plan<N>, bool NTS = false>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false>
 __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -746,7 +820,8 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     const int tile = blockIdx.y;
     constexpr int NB = (HF::NU + C - 1) / C;
     const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
-    const float2* __restrict__ z0 = a.z + (size_t)tile * HF::Z_TILE;
+    const float2* __restrict__ z0 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + (size_t)tile * HF::Z_TILE * (Z16 ? 4 : 8));
+    [[maybe_unused]] const float uu = Z16 ? a.zscale[tile].z : 1.0f;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
     float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
     TwiddleRegs<N, C, T, P, LM> twr;
@@ -771,7 +846,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     const float mx = key_float(kmx);
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
     const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
-    auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N>(z0, nf, u0 + c, -1.0f); };
+    auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z0, nf, u0 + c, -1.0f, uu); };
     auto out = [&](int p, int c, c32 v, int u, int i) {
         const int q = u0 + c;
         if (q > N / 2) return;
