@@ -46,6 +46,10 @@
 #define ORACLE_MODE_FULL7   0   /* all seven fields (reference behaviour)           */
 #define ORACLE_MODE_CHOPPY5 1   /* h, Dx, Dz, slope-x, slope-z; normal.zw = 0        */
 #define ORACLE_MODE_HEIGHT1 2   /* height only; disp.xz = 0, normal = 0              */
+#define ORACLE_MODE_JACOBIAN 3  /* the seven fields + the reference's COMPUTE_JACOBIAN intent (.h:209-224, .cpp:330-335,
+                                 * 368-378, 421-428): two more transforms dz(Dx), dx(Dz) and displacement.w = the Jacobian
+                                 * of the horizontal displacement.  The reference's block does not compile (it names
+                                 * `displacement` outside its scope, .cpp:427); the arithmetic and its order are its own. */
 
 #define ORACLE_FFT_F32 0        /* reference shape: float FFTs, one thread per 2-D transform */
 #define ORACLE_FFT_F64 1        /* float front end, FFT + pack in double              */
@@ -115,12 +119,12 @@ typedef struct oracle_ctx {
     /* FFT state */
     plan1d_f pf;
     plan1d_d pd;
-    cpx_f* ff;               /* 7*n*n, one block like WSTessendorf.cpp:164-171 */
+    cpx_f* ff;               /* 9*n*n, one block like WSTessendorf.cpp:158-174 (kTotalInputs = 7 + 2 with COMPUTE_JACOBIAN) */
     cpx_d* fd;               /* 7*n*n, only for ORACLE_FFT_F64 */
     cpx_f* work_f;           /* 7 * 17n */
     cpx_d* work_d;
     cpx_f* work_team;        /* threads * 17n, ORACLE_FFT_F32_TEAM */
-    void* fftw_plans[7];     /* ORACLE_FFT_FFTW: one in-place plan per field, like WSTessendorf.cpp:191-232 */
+    void* fftw_plans[9];     /* ORACLE_FFT_FFTW: one in-place plan per field, like WSTessendorf.cpp:191-232 */
     oracle_fft_cb ext_fft;   /* ORACLE_FFT_EXTERNAL */
     void* ext_fft_user;
     double stage_ms[4];      /* wall time of the last frame's stages: A-C spectra, D transforms, E-F pack, G normalise */
@@ -195,7 +199,7 @@ static void free_buffers(oracle_ctx* c)
     free(c->kvec); free(c->kunit); free(c->h0); free(c->h0c); free(c->omega); free(c->xi);
     free(c->disp); free(c->nrm); free(c->ff); free(c->fd); free(c->work_f); free(c->work_d); free(c->work_team);
     c->work_team = NULL;
-    for (int f = 0; f < 7; ++f)
+    for (int f = 0; f < 9; ++f)
         if (c->fftw_plans[f]) { g_fftw.destroy(c->fftw_plans[f]); c->fftw_plans[f] = NULL; }
     c->kvec = c->kunit = c->h0 = c->h0c = c->omega = c->xi = c->disp = c->nrm = NULL;
     c->ff = NULL; c->fd = NULL; c->work_f = NULL; c->work_d = NULL;
@@ -282,8 +286,8 @@ int oracle_prepare(oracle_ctx* c, uint64_t seed, const float* xi_or_null)
     c->xi = (float*)malloc(n2 * 2 * sizeof(float));
     c->disp = (float*)malloc(n2 * 4 * sizeof(float));
     c->nrm = (float*)malloc(n2 * 4 * sizeof(float));
-    c->ff = (cpx_f*)malloc(n2 * 7 * sizeof(cpx_f));
-    c->work_f = (cpx_f*)malloc((size_t)7 * 17 * n * sizeof(cpx_f));
+    c->ff = (cpx_f*)malloc(n2 * 9 * sizeof(cpx_f));
+    c->work_f = (cpx_f*)malloc((size_t)9 * 17 * n * sizeof(cpx_f));
     if (!c->kvec || !c->kunit || !c->h0 || !c->h0c || !c->omega || !c->xi || !c->disp || !c->nrm ||
         !c->ff || !c->work_f)
         return -2;
@@ -367,10 +371,12 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
     cpx_f* d_z = d_x + n2;
     cpx_f* dxd_x = d_z + n2;
     cpx_f* dzd_z = dxd_x + n2;
-    const int nfields = mode == ORACLE_MODE_FULL7 ? 7 : (mode == ORACLE_MODE_CHOPPY5 ? 5 : 1);
+    cpx_f* dzd_x = dzd_z + n2;       /* .cpp:171-174 */
+    cpx_f* dxd_z = dzd_x + n2;
+    const int nfields = mode == ORACLE_MODE_JACOBIAN ? 9 : (mode == ORACLE_MODE_FULL7 ? 7 : (mode == ORACLE_MODE_CHOPPY5 ? 5 : 1));
     if (fft_kind == ORACLE_FFT_F64 && !c->fd) {
-        c->fd = (cpx_d*)malloc(n2 * 7 * sizeof(cpx_d));
-        c->work_d = (cpx_d*)malloc((size_t)7 * 17 * n * sizeof(cpx_d));
+        c->fd = (cpx_d*)malloc(n2 * 9 * sizeof(cpx_d));
+        c->work_d = (cpx_d*)malloc((size_t)9 * 17 * n * sizeof(cpx_d));
         if (!c->fd || !c->work_d) return NAN;
     }
 
@@ -380,7 +386,7 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
     }
     if (fft_kind == ORACLE_FFT_FFTW) {
         if (!oracle_fftw_available()) return NAN;
-        for (int f = 0; f < 7; ++f)      /* SetupFFTW, .cpp:191-232: in place, FFTW_BACKWARD, FFTW_MEASURE (planning clobbers the arrays: done before they are filled) */
+        for (int f = 0; f < 9; ++f)      /* SetupFFTW, .cpp:191-246: in place, FFTW_BACKWARD, FFTW_MEASURE (planning clobbers the arrays: done before they are filled) */
             if (!c->fftw_plans[f]) c->fftw_plans[f] = g_fftw.plan((int)n, (int)n, c->ff + (size_t)f * n2, c->ff + (size_t)f * n2, +1, 0u);
     }
 
@@ -415,10 +421,14 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
                 cpx_f mux = { 0.0f, -c->kunit[2 * i] }, muz = { 0.0f, -c->kunit[2 * i + 1] };
                 d_x[i] = cmul(mux, height[i]);
                 d_z[i] = cmul(muz, height[i]);
-                if (nfields == 7) {
+                if (nfields >= 7) {
                     cpx_f ikx = { 0.0f, c->kvec[2 * i] }, ikz = { 0.0f, c->kvec[2 * i + 1] };
                     dxd_x[i] = cmul(ikx, d_x[i]);
                     dzd_z[i] = cmul(ikz, d_z[i]);
+                    if (nfields == 9) {          /* .cpp:330-335 */
+                        dzd_x[i] = cmul(ikz, d_x[i]);
+                        dxd_z[i] = cmul(ikx, d_z[i]);
+                    }
                 }
             }
         }
@@ -492,8 +502,16 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
                 float* o = c->nrm + 4 * i;
                 o[0] = nfields >= 5 ? (float)sgn * slope_x[i].re : 0.0f;
                 o[1] = nfields >= 5 ? (float)sgn * slope_z[i].re : 0.0f;
-                o[2] = nfields == 7 ? (float)sgn * dxd_x[i].re : 0.0f;
-                o[3] = nfields == 7 ? (float)sgn * dzd_z[i].re : 0.0f;
+                o[2] = nfields >= 7 ? (float)sgn * dxd_x[i].re : 0.0f;
+                o[3] = nfields >= 7 ? (float)sgn * dzd_z[i].re : 0.0f;
+                if (nfields == 9) {              /* .cpp:421-428, written to displacement.w as the shaders read it (.vert:29, .frag:210-212) */
+                    const float jacobian =
+                        (1.0f + lambda * (float)sgn * dxd_x[i].re) *
+                        (1.0f + lambda * (float)sgn * dzd_z[i].re) -
+                        (lambda * (float)sgn * dxd_z[i].re) *
+                        (lambda * (float)sgn * dzd_x[i].re);
+                    c->disp[4 * i + 3] = jacobian;
+                }
             }
     }
     const double t_pack = wall_ms();

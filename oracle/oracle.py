@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libocean_oracle.so")
 
-MODE_FULL7, MODE_CHOPPY5, MODE_HEIGHT1 = 0, 1, 2
+MODE_FULL7, MODE_CHOPPY5, MODE_HEIGHT1, MODE_JACOBIAN = 0, 1, 2, 3
 FFT_F32, FFT_F64, FFT_F32_TEAM, FFT_FFTW, FFT_EXTERNAL = 0, 1, 2, 3, 4     # see ocean_oracle.c
 
 
@@ -256,8 +256,10 @@ def numpy_prepare(n, xi, length=1000.0, wind=(1.0, 1.0), wind_speed=30.0, anim_p
     return dict(kx=kx, kz=kz, ux=ux, uz=uz, h0=(h0r + 1j * h0i).astype(np.complex64), omega=om.astype(f32))
 
 
-def numpy_compute_waves(prep, t, lam=-1.0):
-    """Closed form of WSTessendorf.cpp:284-455 with float64 FFTs."""
+def numpy_compute_waves(prep, t, lam=-1.0, jacobian=False):
+    """Closed form of WSTessendorf.cpp:284-455 with float64 FFTs.  jacobian=True adds the
+    reference's COMPUTE_JACOBIAN intent (.cpp:330-335, 421-428): displacement.w = (1 + lam dxDx)(1 + lam dzDz) -
+    (lam dxDz)(lam dzDx)."""
     import scipy.fft as sfft
     f32 = np.float32
     n = prep["kx"].shape[0]
@@ -282,6 +284,11 @@ def numpy_compute_waves(prep, t, lam=-1.0):
     hmin = min(float(h.min()), float(np.finfo(np.float32).max))
     hmax = max(float(h.max()), float(np.finfo(np.float32).tiny))           # .cpp:289 quirk
     amp = max(abs(hmin), abs(hmax))
-    disp = np.stack([lam * dx, h / amp, lam * dz, np.ones_like(h)], axis=-1)
+    w = np.ones_like(h)
+    if jacobian:
+        dzdx = sign * bre(kz * ux * hr)          # i kz * (-i ux) = kz ux
+        dxdz = sign * bre(kx * uz * hr)
+        w = (1.0 + lam * dxdx) * (1.0 + lam * dzdz) - (lam * dxdz) * (lam * dzdx)
+    disp = np.stack([lam * dx, h / amp, lam * dz, w], axis=-1)
     nrm = np.stack([sx, sz, dxdx, dzdz], axis=-1)
     return amp, disp, nrm, hmin, hmax

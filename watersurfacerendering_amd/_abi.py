@@ -57,7 +57,7 @@ class Params(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ocean_api.hip", "ocean_kernels.h", "fft_engine.h", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"))
     stale = (not os.path.exists(_BUILT_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_BUILT_LIB) for s in srcs)
     if force or stale:

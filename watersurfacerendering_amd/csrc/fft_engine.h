@@ -28,7 +28,7 @@ using c32 = float2;
 
 // diagnostic builds only (-DOCEAN_STAMPS): per-workgroup clock stamps
 #ifdef OCEAN_STAMPS
-__device__ unsigned long long* g_stamps = nullptr;
+static __device__ unsigned long long* g_stamps = nullptr;
 __device__ __forceinline__ void stamp(int k)
 {
     if (threadIdx.x == 0 && g_stamps)

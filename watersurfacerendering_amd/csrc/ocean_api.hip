@@ -2,9 +2,6 @@
 // over the gfx950 kernels of ocean_kernels.h.  C++17, HIP runtime only (no
 // hipFFT/rocFFT, no torch types).  There is no CPU fallback anywhere in this
 // file: without a usable device every entry point returns an error.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-#include <rccl/rccl.h>      // types and prototypes only: the library is loaded with dlopen when a communicator is asked for
 #include <dlfcn.h>
 
 #include <cmath>
@@ -14,8 +11,8 @@
 #include <new>
 #include <vector>
 
-#include "../../include/ocean.h"
-#include "ocean_kernels.h"
+#define OCEAN_INIT_KERNELS      // this translation unit also holds the Prepare() and consumer kernels
+#include "ocean_ctx.h"
 
 using namespace ocean;
 
@@ -30,83 +27,8 @@ static thread_local int g_last_hip = 0;
         }                                               \
     } while (0)
 
-static constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
-
-struct ocean_ctx {
-    uint32_t n = 0;
-    uint32_t tiles = 0;
-    int device = 0;
-    bool prepared = false;
-    // At pipeline depth D asynchronous frames rotate over D chains, each with its own
-    // stream, intermediates and internal map set and no dependency on the others, so the
-    // z pass of one frame overlaps the map passes of the others.  A caller-supplied
-    // stream, caller-bound output or depth 1 runs everything on one stream / set 0.
-    hipStream_t own[MAXD] = {};
-    hipStream_t user = nullptr;
-    int depth = 1;
-    uint64_t frame_ctr = 0;
-    bool have_frame = false;        // a frame has been enqueued since the last ocean_prepare
-    int dispersion = 0;             // ocean_set_dispersion
-    float dispersion_param = 0.0f;
-    int last_set = 0;
-    uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
-    bool lambda_uniform = true;
-    bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)
-
-    std::vector<ocean_params> params;
-    uint64_t seed = 0;
-    // device state
-    float2* h0 = nullptr;
-    float* omega = nullptr;
-    uint16_t* omega_q = nullptr;    // omega / base_freq as 16-bit integers (what the frame kernels read)
-    float* base_freq = nullptr;     // [tiles]
-    unsigned* omega_q_overflow = nullptr;
-    bool omega16 = false;           // every multiple fits 16 bits (decided at ocean_prepare)
-    float* k1d = nullptr;
-    float2* tw = nullptr;
-    float2* z[MAXD] = {};
-    float2* zh[MAXD] = {};
-    float* hraw[MAXD] = {};
-    unsigned* minmax[MAXD] = {};
-    unsigned* mm_host[MAXD] = {};   // pinned, device-visible copy of minmax written by the last kernel of a frame
-    float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
-    float4* nrmN[MAXD] = {};
-    float4* ext_disp = nullptr;
-    float4* ext_nrm = nullptr;
-    float* toff = nullptr;
-    bool use_toff = false;
-    float* lambda = nullptr;
-    TileParams* tparams = nullptr;
-    float2* xi = nullptr;          // injected or generated draws (kept for read-back)
-    int mode = 0;                  // OCEAN_MODE_*
-    int inter_bits_zeroed = 32;    // layout the intermediates' padding was last zero-filled for
-    int inter_bits = 32;           // 32, or 16: the z-pass outputs (z, zh) are stored as scaled half2 (ocean_set_intermediate_precision)
-    float4* zscale = nullptr;      // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k)
-    unsigned* zbounds = nullptr;   // [tiles][2] float bits of the column-sum bounds (k_inter_bounds)
-    int h0_bits = 32;              // 32, or 16: frames read a scaled half2 copy of h0
-    __half2* h0h = nullptr;
-    float* h0_inv_scale = nullptr;
-    unsigned* h0_maxbits = nullptr;
-    unsigned* h_minmax = nullptr;  // pinned
-    float4* grid_pos = nullptr;     // vertex-stage consumer output (ocean_displace_grid)
-    float4* grid_nrm = nullptr;
-    uint32_t grid_vertices = 0, grid_capacity = 0;
-    unsigned long long* stamps = nullptr;   // diagnostic builds only
-    hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
-    hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
-    hipEvent_t mark_ev[MAXD][6] = {};   // per-launch timing: (start, stop) of each of the three kernels of a frame
-    // ---- packed-map gather over RCCL (ocean_comm_init / ocean_gather_maps)
-    ncclComm_t comm = nullptr;
-    int comm_ranks = 0, comm_rank = -1;
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t frame_done[MAXD] = {};   // recorded on a chain's stream behind the frame whose maps are gathered
-    hipEvent_t gather_done[MAXD] = {};  // recorded on the communication stream behind that gather
-    bool gather_pending[MAXD] = {};     // the chain's next frame must wait for gather_done before rewriting the maps
-};
-
 static void free_set(ocean_ctx* c, int i);
 static void comm_release(ocean_ctx* c);
-static hipStream_t stream_of(const ocean_ctx* c, int set);
 
 static void free_device(ocean_ctx* c)
 {
@@ -192,8 +114,6 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMemcpy(c->tw, tw.data(), n * sizeof(float2), hipMemcpyHostToDevice));
     return OCEAN_OK;
 }
-
-static hipStream_t stream_of(const ocean_ctx* c, int set) { return c->user ? c->user : c->own[set]; }
 
 static int sync_all(ocean_ctx* c)
 {
@@ -454,119 +374,12 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
 
 // ---------------------------------------------------------------------------------
 // frame launch
-template <int N> static const char* kernel_name_of(int idx)
+static const char* kernel_name_of(int idx)
 {
     if (idx == 0) return "k_zpass";
     if (idx == 1) return "k_xpass_b";
     if (idx == 2) return "k_xpass_disp";
     return nullptr;
-}
-
-
-// ---------------------------------------------------------------------------------
-template <class K>
-static hipError_t allow_lds(K kernel, size_t bytes)
-{
-    if (bytes <= 48 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes);
-}
-
-// One kernel launch.  With an event pair the launch goes through hipExtLaunchKernelGGL, which attaches the events
-// to the dispatch itself: their interval is the kernel's own execution time (what rocprofv3 reports), free of the
-// 2.5-3 us of marker/launch processing that events recorded around a launch carry.
-template <class K, class... A>
-static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t* ev, A... args)
-{
-    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, ev[0], ev[1], 0, args...);
-    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
-}
-
-template <int N>
-static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
-                               hipStream_t st, hipEvent_t* marks /* 6 events (start, stop per kernel) or null */)
-{
-    using G = Geo<N>;
-    using HF = Half<N>;
-    const unsigned tiles = c->tiles;
-    hipError_t e;
-    constexpr int C = G::CC;
-    constexpr size_t lds_rows = zpass_lds_bytes<N>();
-    constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
-    constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
-    static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
-    constexpr unsigned hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
-    // function attributes are per device; a context belongs to one device and one thread, so the flag
-    // lives in the context (no process-wide state shared between contexts or threads)
-    if (c->attr_n != (uint32_t)N) {
-#define OCEAN_ALLOW_Z(h16, w16, znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, lds_rows)) != hipSuccess) return e;
-#define OCEAN_ALLOW_Z4(h16, w16) OCEAN_ALLOW_Z(h16, w16, false, false) OCEAN_ALLOW_Z(h16, w16, true, false) OCEAN_ALLOW_Z(h16, w16, false, true) OCEAN_ALLOW_Z(h16, w16, true, true)
-        OCEAN_ALLOW_Z4(false, false) OCEAN_ALLOW_Z4(true, false) OCEAN_ALLOW_Z4(false, true) OCEAN_ALLOW_Z4(true, true)
-#undef OCEAN_ALLOW_Z4
-#undef OCEAN_ALLOW_Z
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, false>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, false>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, true>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, true>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, false>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, false>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, true>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, true>, lds_m)) != hipSuccess) return e;
-        c->attr_n = (uint32_t)N;
-    }
-#ifdef OCEAN_STAMPS
-    // diagnostic: stamps are recorded for ONE kernel of the frame (env OCEAN_DEBUG_STAMP_KERNEL = 0, 1, 2)
-    static unsigned long long* null_ptr = nullptr;
-    const int stamp_k = getenv("OCEAN_DEBUG_STAMP_KERNEL") ? atoi(getenv("OCEAN_DEBUG_STAMP_KERNEL")) : 0;
-    auto arm = [&](int k) {
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(ocean::g_stamps), (k == stamp_k && c->stamps) ? &c->stamps : &null_ptr,
-                                     sizeof(c->stamps), 0, hipMemcpyHostToDevice, st);
-    };
-    arm(0);
-#endif
-    {
-        unsigned gx = N / 2 + 1;
-#ifdef OCEAN_STAMPS
-        if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
-#endif
-        const dim3 grid(gx, tiles), block(G::T_ROWS);
-#define OCEAN_ZPASS(h16, w16, znt) \
-        do { if (stream_maps & 8) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, true>, grid, block, lds_rows, st, marks, a); \
-             else launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, false>, grid, block, lds_rows, st, marks, a); } while (0)
-        const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
-        switch (variant) {
-            case 0: OCEAN_ZPASS(false, false, false); break;
-            case 1: OCEAN_ZPASS(false, false, true); break;
-            case 2: OCEAN_ZPASS(false, true, false); break;
-            case 3: OCEAN_ZPASS(false, true, true); break;
-            case 4: OCEAN_ZPASS(true, false, false); break;
-            case 5: OCEAN_ZPASS(true, false, true); break;
-            case 6: OCEAN_ZPASS(true, true, false); break;
-            default: OCEAN_ZPASS(true, true, true); break;
-        }
-#undef OCEAN_ZPASS
-    }
-#ifdef OCEAN_STAMPS
-    if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
-    arm(1);
-#endif
-    {
-        const dim3 gb(hb_b + nb, tiles), gd(nb, tiles), blk(G::T_C);
-        hipEvent_t* mb = marks ? marks + 2 : nullptr;
-        hipEvent_t* md = marks ? marks + 4 : nullptr;
-#define OCEAN_XPASS(kern, grid, lds, ev, nts)                                                                       \
-        do { if (stream_maps & 8) launch(kern<N, C, G::T_C, typename G::PC, nts, true>, grid, blk, lds, st, ev, a);    \
-             else launch(kern<N, C, G::T_C, typename G::PC, nts, false>, grid, blk, lds, st, ev, a); } while (0)
-        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true);
-        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false);
-#ifdef OCEAN_STAMPS
-        arm(2);
-#endif
-        if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true);
-        else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false);
-#undef OCEAN_XPASS
-    }
-    return hipGetLastError();
 }
 
 // Enqueues one frame.  pipelined = the call may use the pipeline chains (depth > 1).
@@ -634,18 +447,11 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs): bit mask
     if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 8);
     hipError_t e = hipErrorInvalidValue;
-    switch (c->n) {
-        case 16: e = launch_frame<16>(c, a, stream_maps, st, marks); break;
-        case 32: e = launch_frame<32>(c, a, stream_maps, st, marks); break;
-        case 64: e = launch_frame<64>(c, a, stream_maps, st, marks); break;
-        case 128: e = launch_frame<128>(c, a, stream_maps, st, marks); break;
-        case 256: e = launch_frame<256>(c, a, stream_maps, st, marks); break;
-        case 512: e = launch_frame<512>(c, a, stream_maps, st, marks); break;
-        case 1024: e = launch_frame<1024>(c, a, stream_maps, st, marks); break;
-        case 2048: e = launch_frame<2048>(c, a, stream_maps, st, marks); break;
-        case 4096: e = launch_frame<4096>(c, a, stream_maps, st, marks); break;
-        default: return OCEAN_E_UNSUPPORTED;
-    }
+    if (c->n <= 256) e = ocean_launch_frame_small(c, a, stream_maps, st, marks);
+    else if (c->n <= 1024) e = ocean_launch_frame_mid(c, a, stream_maps, st, marks);
+    else if (c->n == 2048) e = ocean_launch_frame_2048(c, a, stream_maps, st, marks);
+    else if (c->n == 4096) e = ocean_launch_frame_4096(c, a, stream_maps, st, marks);
+    else return OCEAN_E_UNSUPPORTED;
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
     if (pipe) c->frame_ctr++;
     c->have_frame = true;
@@ -1036,19 +842,7 @@ int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, siz
 
 const char* ocean_kernel_name(const ocean_t* c, int idx)
 {
-    if (!c) return nullptr;
-    switch (c->n) {
-        case 16: return kernel_name_of<16>(idx);
-        case 32: return kernel_name_of<32>(idx);
-        case 64: return kernel_name_of<64>(idx);
-        case 128: return kernel_name_of<128>(idx);
-        case 256: return kernel_name_of<256>(idx);
-        case 512: return kernel_name_of<512>(idx);
-        case 1024: return kernel_name_of<1024>(idx);
-        case 2048: return kernel_name_of<2048>(idx);
-        case 4096: return kernel_name_of<4096>(idx);
-        default: return nullptr;
-    }
+    return c ? kernel_name_of(idx) : nullptr;
 }
 
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)

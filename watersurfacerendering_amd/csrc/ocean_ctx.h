@@ -1,0 +1,97 @@
+// ocean_ctx.h -- the context behind the opaque ocean_t of include/ocean.h, shared by the translation units of
+// libocean_hip.so (ocean_api.hip: the C ABI; frames_*.hip: the per-size frame launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is loaded with dlopen when a communicator is asked for
+
+#include <vector>
+
+#include "../../include/ocean.h"
+#include "ocean_kernels.h"
+
+constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
+
+struct ocean_ctx {
+    uint32_t n = 0;
+    uint32_t tiles = 0;
+    int device = 0;
+    bool prepared = false;
+    // At pipeline depth D asynchronous frames rotate over D chains, each with its own
+    // stream, intermediates and internal map set and no dependency on the others, so the
+    // z pass of one frame overlaps the map passes of the others.  A caller-supplied
+    // stream, caller-bound output or depth 1 runs everything on one stream / set 0.
+    hipStream_t own[MAXD] = {};
+    hipStream_t user = nullptr;
+    int depth = 1;
+    uint64_t frame_ctr = 0;
+    bool have_frame = false;        // a frame has been enqueued since the last ocean_prepare
+    int dispersion = 0;             // ocean_set_dispersion
+    float dispersion_param = 0.0f;
+    int last_set = 0;
+    uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
+    bool lambda_uniform = true;
+    bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)
+
+    std::vector<ocean_params> params;
+    uint64_t seed = 0;
+    // device state
+    float2* h0 = nullptr;
+    float* omega = nullptr;
+    uint16_t* omega_q = nullptr;    // omega / base_freq as 16-bit integers (what the frame kernels read)
+    float* base_freq = nullptr;     // [tiles]
+    unsigned* omega_q_overflow = nullptr;
+    bool omega16 = false;           // every multiple fits 16 bits (decided at ocean_prepare)
+    float* k1d = nullptr;
+    float2* tw = nullptr;
+    float2* z[MAXD] = {};
+    float2* zh[MAXD] = {};
+    float* hraw[MAXD] = {};
+    unsigned* minmax[MAXD] = {};
+    unsigned* mm_host[MAXD] = {};   // pinned, device-visible copy of minmax written by the last kernel of a frame
+    float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
+    float4* nrmN[MAXD] = {};
+    float4* ext_disp = nullptr;
+    float4* ext_nrm = nullptr;
+    float* toff = nullptr;
+    bool use_toff = false;
+    float* lambda = nullptr;
+    ocean::TileParams* tparams = nullptr;
+    float2* xi = nullptr;          // injected or generated draws (kept for read-back)
+    int mode = 0;                  // OCEAN_MODE_*
+    int inter_bits_zeroed = 32;    // layout the intermediates' padding was last zero-filled for
+    int inter_bits = 32;           // 32, or 16: the z-pass outputs (z, zh) are stored as scaled half2 (ocean_set_intermediate_precision)
+    float4* zscale = nullptr;      // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k)
+    unsigned* zbounds = nullptr;   // [tiles][2] float bits of the column-sum bounds (k_inter_bounds)
+    int h0_bits = 32;              // 32, or 16: frames read a scaled half2 copy of h0
+    __half2* h0h = nullptr;
+    float* h0_inv_scale = nullptr;
+    unsigned* h0_maxbits = nullptr;
+    unsigned* h_minmax = nullptr;  // pinned
+    float4* grid_pos = nullptr;     // vertex-stage consumer output (ocean_displace_grid)
+    float4* grid_nrm = nullptr;
+    uint32_t grid_vertices = 0, grid_capacity = 0;
+    unsigned long long* stamps = nullptr;   // diagnostic builds only
+    hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
+    hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
+    hipEvent_t mark_ev[MAXD][6] = {};   // per-launch timing: (start, stop) of each of the three kernels of a frame
+    // ---- packed-map gather over RCCL (ocean_comm_init / ocean_gather_maps)
+    ncclComm_t comm = nullptr;
+    int comm_ranks = 0, comm_rank = -1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t frame_done[MAXD] = {};   // recorded on a chain's stream behind the frame whose maps are gathered
+    hipEvent_t gather_done[MAXD] = {};  // recorded on the communication stream behind that gather
+    bool gather_pending[MAXD] = {};     // the chain's next frame must wait for gather_done before rewriting the maps
+};
+
+
+inline hipStream_t stream_of(const ocean_ctx* c, int set) { return c->user ? c->user : c->own[set]; }
+
+// One frame = three launches on `st` (ocean_launch.h); one entry point per group of tile sizes, each compiled in its
+// own translation unit (frames_*.hip) so that the library builds in parallel.  stream_maps: bit 0 normal map and
+// bit 1 displacement map stored non-temporally, bit 2 intermediates stored non-temporally, bit 3 half2 intermediates.
+// marks: 6 events (start, stop per kernel) or null.
+hipError_t ocean_launch_frame_small(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);   // 16 .. 256
+hipError_t ocean_launch_frame_mid(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);     // 512, 1024
+hipError_t ocean_launch_frame_2048(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);
+hipError_t ocean_launch_frame_4096(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);

@@ -172,6 +172,7 @@ __host__ __device__ inline float key_float(unsigned k)
     return v.f;
 }
 
+#ifdef OCEAN_INIT_KERNELS
 // ============================================================================
 // Prepare(): wave vectors (.cpp:60-85), gaussian draws (.cpp:87-103, RNG
 // replaced by a counter-based one), base spectrum + dispersion (.cpp:105-148).
@@ -332,6 +333,8 @@ __global__ void k_inter_bounds(const float2* __restrict__ h0, const float* __res
         atomicMax(bounds + 2 * tile + 1, __float_as_uint(tk));
     }
 }
+
+#endif  // OCEAN_INIT_KERNELS
 
 // ============================================================================
 // h~(k, t): WaveHeightFT (.h:265-275).  conj(h0(-k)) of the reference equals
@@ -863,6 +866,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 }
 
+#ifdef OCEAN_INIT_KERNELS
 // ============================================================================
 // Vertex-stage consumer: what the reference's vertex shader does with
 // the two maps (src/shaders/WaterSurfaceMesh.vert:24-41) for the grid its mesh generator
@@ -925,6 +929,8 @@ __global__ void k_displace_grid(const GridArgs g)
     const float len = sqrtf(nx * nx + 1.0f + nz * nz);
     g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
 }
+
+#endif  // OCEAN_INIT_KERNELS
 
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;

@@ -1,0 +1,114 @@
+// ocean_launch.h -- launch_frame<N>: the three launches of one frame at tile size N (included by frames_*.hip).
+#pragma once
+#include <cstdlib>
+
+#include "ocean_ctx.h"
+
+using namespace ocean;
+
+// ---------------------------------------------------------------------------------
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+// One kernel launch.  With an event pair the launch goes through hipExtLaunchKernelGGL, which attaches the events
+// to the dispatch itself: their interval is the kernel's own execution time (what rocprofv3 reports), free of the
+// 2.5-3 us of marker/launch processing that events recorded around a launch carry.
+template <class K, class... A>
+static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t* ev, A... args)
+{
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, ev[0], ev[1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+
+template <int N>
+static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
+                               hipStream_t st, hipEvent_t* marks /* 6 events (start, stop per kernel) or null */)
+{
+    using G = Geo<N>;
+    using HF = Half<N>;
+    const unsigned tiles = c->tiles;
+    hipError_t e;
+    constexpr int C = G::CC;
+    constexpr size_t lds_rows = zpass_lds_bytes<N>();
+    constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
+    constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
+    static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
+    constexpr unsigned hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
+    // function attributes are per device; a context belongs to one device and one thread, so the flag
+    // lives in the context (no process-wide state shared between contexts or threads)
+    if (c->attr_n != (uint32_t)N) {
+#define OCEAN_ALLOW_Z(h16, w16, znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, lds_rows)) != hipSuccess) return e;
+#define OCEAN_ALLOW_Z4(h16, w16) OCEAN_ALLOW_Z(h16, w16, false, false) OCEAN_ALLOW_Z(h16, w16, true, false) OCEAN_ALLOW_Z(h16, w16, false, true) OCEAN_ALLOW_Z(h16, w16, true, true)
+        OCEAN_ALLOW_Z4(false, false) OCEAN_ALLOW_Z4(true, false) OCEAN_ALLOW_Z4(false, true) OCEAN_ALLOW_Z4(true, true)
+#undef OCEAN_ALLOW_Z4
+#undef OCEAN_ALLOW_Z
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, false>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, false>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, true>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, true>, lds_b)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, false>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, false>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, true>, lds_m)) != hipSuccess) return e;
+        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, true>, lds_m)) != hipSuccess) return e;
+        c->attr_n = (uint32_t)N;
+    }
+#ifdef OCEAN_STAMPS
+    // diagnostic: stamps are recorded for ONE kernel of the frame (env OCEAN_DEBUG_STAMP_KERNEL = 0, 1, 2)
+    static unsigned long long* null_ptr = nullptr;
+    const int stamp_k = getenv("OCEAN_DEBUG_STAMP_KERNEL") ? atoi(getenv("OCEAN_DEBUG_STAMP_KERNEL")) : 0;
+    auto arm = [&](int k) {
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(ocean::g_stamps), (k == stamp_k && c->stamps) ? &c->stamps : &null_ptr,
+                                     sizeof(c->stamps), 0, hipMemcpyHostToDevice, st);
+    };
+    arm(0);
+#endif
+    {
+        unsigned gx = N / 2 + 1;
+#ifdef OCEAN_STAMPS
+        if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
+#endif
+        const dim3 grid(gx, tiles), block(G::T_ROWS);
+#define OCEAN_ZPASS(h16, w16, znt) \
+        do { if (stream_maps & 8) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, true>, grid, block, lds_rows, st, marks, a); \
+             else launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, false>, grid, block, lds_rows, st, marks, a); } while (0)
+        const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
+        switch (variant) {
+            case 0: OCEAN_ZPASS(false, false, false); break;
+            case 1: OCEAN_ZPASS(false, false, true); break;
+            case 2: OCEAN_ZPASS(false, true, false); break;
+            case 3: OCEAN_ZPASS(false, true, true); break;
+            case 4: OCEAN_ZPASS(true, false, false); break;
+            case 5: OCEAN_ZPASS(true, false, true); break;
+            case 6: OCEAN_ZPASS(true, true, false); break;
+            default: OCEAN_ZPASS(true, true, true); break;
+        }
+#undef OCEAN_ZPASS
+    }
+#ifdef OCEAN_STAMPS
+    if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
+    arm(1);
+#endif
+    {
+        const dim3 gb(hb_b + nb, tiles), gd(nb, tiles), blk(G::T_C);
+        hipEvent_t* mb = marks ? marks + 2 : nullptr;
+        hipEvent_t* md = marks ? marks + 4 : nullptr;
+#define OCEAN_XPASS(kern, grid, lds, ev, nts)                                                                       \
+        do { if (stream_maps & 8) launch(kern<N, C, G::T_C, typename G::PC, nts, true>, grid, blk, lds, st, ev, a);    \
+             else launch(kern<N, C, G::T_C, typename G::PC, nts, false>, grid, blk, lds, st, ev, a); } while (0)
+        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true);
+        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false);
+#ifdef OCEAN_STAMPS
+        arm(2);
+#endif
+        if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true);
+        else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false);
+#undef OCEAN_XPASS
+    }
+    return hipGetLastError();
+}
+
