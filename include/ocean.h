@@ -168,7 +168,14 @@ int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
  *   OCEAN_MODE_CHOPPY5  h, Dx, Dz, slope-x, slope-z ("5 iFFTs"); normal.zw = 0
  *   OCEAN_MODE_HEIGHT1  height only; displacement = (0, h/A, 0, 1), normal = 0
  * Takes effect at the next frame (no ocean_prepare needed).                              */
-enum { OCEAN_MODE_FULL7 = 0, OCEAN_MODE_CHOPPY5 = 1, OCEAN_MODE_HEIGHT1 = 2 };
+/*   OCEAN_MODE_JACOBIAN the seven fields plus the reference's COMPUTE_JACOBIAN intent (WSTessendorf.h:209-224,
+ *                       .cpp:330-335, 368-378, 421-428; dead, non-compiling code there): the cross derivative
+ *                       d(Dx)/dz = d(Dz)/dx as an eighth real field, and
+ *                         displacement.w = (1 + l dDx/dx)(1 + l dDz/dz) - (l dDx/dz)(l dDz/dx),   l = lambda,
+ *                       the Jacobian of the horizontal displacement, instead of the constant 1; the reference's
+ *                       shaders already carry it (WaterSurfaceMesh.vert:29) and paint foam where it is negative
+ *                       (WaterSurfaceMesh.frag:210-212).  86 instead of 74 bytes per texel.                  */
+enum { OCEAN_MODE_FULL7 = 0, OCEAN_MODE_CHOPPY5 = 1, OCEAN_MODE_HEIGHT1 = 2, OCEAN_MODE_JACOBIAN = 3 };
 int ocean_set_mode(ocean_t* ctx, int mode);
 
 /* Dispersion relation of the next ocean_prepare (all tiles).  OCEAN_DISPERSION_DEEP (default) is the

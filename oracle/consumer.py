@@ -50,3 +50,10 @@ def displace_grid(disp: np.ndarray, nrm: np.ndarray, amp: float, grid: int, vert
     ln = np.sqrt(nx * nx + F(1.0) + nz * nz)
     out_n = np.stack([nx / ln, F(1.0) / ln, nz / ln, np.zeros_like(nx)], axis=1).astype(np.float32)
     return pos, out_n
+
+
+def foam_mask(positions: np.ndarray) -> np.ndarray:
+    """What the reference's fragment stage does with the interpolated w (WaterSurfaceMesh.frag:210-212:
+    `if (inPos.w < 0.0) color = vec3(1.0)`): per VERTEX here, True where the surface folds over itself -- the
+    Jacobian of the horizontal displacement, carried in displacement.w (WaterSurfaceMesh.vert:29), is negative."""
+    return positions[:, 3] < F(0.0)

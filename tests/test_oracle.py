@@ -223,3 +223,52 @@ def test_sampled_golden_fixtures(path):
         assert np.all(np.abs(mean - g[f"meanabs{i}"]) <= 1e-6 * scale)
         assert np.all(np.abs(d[idx] - g[f"disp{i}"]) <= 2e-6 * scale[:4])
         assert np.all(np.abs(q[idx] - g[f"nrm{i}"]) <= 2e-6 * scale[4:])
+
+
+# ---------------------------------------------------------------------------
+# OCEAN_MODE_JACOBIAN: the reference's COMPUTE_JACOBIAN intent
+def test_jacobian_mode_restates_the_reference_intent():
+    """WSTessendorf.cpp:330-335 builds dz(Dx) = i kz Dx and dx(Dz) = i kx Dz; :421-428 combines them into
+    (1 + l dxDx)(1 + l dzDz) - (l dxDz)(l dzDx).  The C oracle (two separate transforms, float order of the
+    reference) against the numpy closed form; the seven reference fields are untouched by the mode; the two cross
+    fields coincide (kz ux = kx uz); the Jacobian is even under index inversion and tends to 1 as lambda -> 0."""
+    from oracle import oracle as O
+    n, t = 64, 2.5
+    xi = O.gauss_xi_numpy(5, n)
+    for lam in (-1.0, -1.7):
+        o = O.Oracle(n, lam=lam)
+        o.prepare(xi=xi)
+        a, d, q = o.compute_waves(t, mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+        dzdx, dxdz = o.field(7).real.copy(), o.field(8).real.copy()
+        a7, d7, q7 = o.compute_waves(t, mode=O.MODE_FULL7, fft=O.FFT_F64)
+        assert a == a7 and np.array_equal(d[..., :3], d7[..., :3]) and np.array_equal(q, q7)
+        assert np.all(d7[..., 3] == 1.0)
+        assert np.abs(dzdx - dxdz).max() <= 1e-5 * np.abs(dxdz).max()
+        prep = O.numpy_prepare(n, xi)
+        _, dn, _, _, _ = O.numpy_compute_waves(prep, t, lam=lam, jacobian=True)
+        assert np.abs(d[..., 3] - dn[..., 3]).max() <= 2e-6 * np.abs(dn[..., 3]).max()
+        w = d[..., 3]
+        wm = np.roll(w[::-1, ::-1], (1, 1), axis=(0, 1))              # w at ((N-m)%N, (N-n)%N)
+        assert np.abs(w - wm).max() <= 1e-5
+        assert w.min() < 1.0 < w.max()
+    o = O.Oracle(n, lam=-1e-4)
+    o.prepare(xi=xi)
+    _, d, _ = o.compute_waves(t, mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+    assert np.abs(d[..., 3] - 1.0).max() < 1e-3
+
+
+def test_foam_mask_follows_the_fragment_stage():
+    """WaterSurfaceMesh.frag:210-212 paints white where the interpolated w is negative; with stronger choppiness more
+    of the surface folds."""
+    from oracle import oracle as O
+    from oracle import consumer as C
+    n = 64
+    xi = O.gauss_xi_numpy(5, n)
+    frac = []
+    for lam in (-0.5, -1.5, -3.0):
+        o = O.Oracle(n, lam=lam)
+        o.prepare(xi=xi)
+        a, d, q = o.compute_waves(1.0, mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+        pos, _ = C.displace_grid(d, q, a, n, 1000.0 / 512.0, 1.0, lam)
+        frac.append(float(C.foam_mask(pos).mean()))
+    assert frac[0] <= frac[1] <= frac[2] and frac[2] > 0.0 and frac[0] < 0.01

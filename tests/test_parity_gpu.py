@@ -324,7 +324,7 @@ def test_errors_and_ordering():
     b.set_tile_size(32)                       # resize invalidates the prepared state
     with pytest.raises(W.OceanError):
         b.compute_waves(0.0)
-    for bad in (lambda: b.set_mode(3), lambda: b.set_pipeline_depth(0), lambda: b.set_pipeline_depth(99),
+    for bad in (lambda: b.set_mode(4), lambda: b.set_pipeline_depth(0), lambda: b.set_pipeline_depth(99),
                 lambda: b.set_spectrum_precision(8)):
         with pytest.raises(W.OceanError):
             bad()
@@ -622,4 +622,73 @@ def test_fp16_intermediates_within_stated_tolerance(n, params):
     b.prepare(seed)
     assert b.algorithmic_bytes_per_texel == 74
     check_frame(b, o, 4.5)
+    b.close()
+
+
+# ---------------------------------------------------------------------------
+# Jacobian / foam channel
+@pytest.mark.parametrize("n,lam", [(16, -1.0), (64, -1.7), (256, -1.0), (512, -2.0), (2048, -1.0)])
+def test_jacobian_mode_matches_oracle(n, lam):
+    """OCEAN_MODE_JACOBIAN: displacement.w = (1 + l dxDx)(1 + l dzDz) - (l dxDz)(l dzDx) (the intent of
+    WSTessendorf.cpp:330-335, 421-428) against the oracle's two-transform restatement, within 1e-5 of max|w|;
+    the seven reference fields are exactly what FULL7 gives; lambda reaches the Jacobian without Prepare; the mode
+    combines with pipelining (bit-identical) and with the half2 intermediates (1e-3)."""
+    from oracle import oracle as O
+    from watersurfacerendering_amd import _abi
+    seed = 0x5EED0000 + 5
+    b = make_gpu(n, None, seed=seed, lam=lam)
+    o = make_oracle(n, b.read_xi(0), lam=lam)
+    t = 2.25
+    b.compute_waves(t)
+    d7, q7 = b.read_maps()
+    b.set_mode(_abi.OCEAN_MODE_JACOBIAN)
+    assert b.algorithmic_bytes_per_texel == 86
+    ag = float(b.compute_waves(t)[0])
+    dg, ng = b.read_maps()
+    ao, do, no = o.compute_waves(t, mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+    assert abs(ag - ao) <= TOL_AMP * ao
+    assert max(chan_err(dg[0], do)) <= TOL and max(chan_err(ng[0], no)) <= TOL
+    assert float(np.abs(do[..., 3] - 1.0).max()) > 0.05                      # the channel is not the constant 1 any more
+    assert np.array_equal(ng, q7) and np.array_equal(dg[..., 0], d7[..., 0]) and np.array_equal(dg[..., 2], d7[..., 2])
+    assert np.abs(dg[..., 1] - d7[..., 1]).max() <= 2e-6                     # the height goes through pair 3 instead of the real-row transform
+    # SetLambda without Prepare (.cpp:497-500) reaches the Jacobian too
+    b.set_lambda(0.5 * lam); o.set_lambda(0.5 * lam)
+    b.compute_waves(t)
+    d2, _ = b.read_maps()
+    _, do2, _ = o.compute_waves(t, mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+    assert max(chan_err(d2[0], do2)) <= TOL
+    # pipelined: bit-identical
+    b.set_pipeline_depth(3)
+    for tt in (0.3, 0.6, t):
+        b.compute_waves_async(tt)
+    b.synchronize()
+    d3, _ = b.read_maps()
+    assert np.array_equal(d2, d3)
+    b.set_pipeline_depth(1)
+    # with the reduced-precision intermediates
+    b.set_intermediate_precision(16)
+    b.prepare(seed)
+    assert b.algorithmic_bytes_per_texel == 70
+    b.compute_waves(t)
+    d16, n16 = b.read_maps()
+    assert max(chan_err(d16[0], do2)) <= Z16_TOL and max(chan_err(n16[0], no)) <= Z16_TOL
+    b.close()
+
+
+def test_jacobian_reaches_the_vertex_stage_consumer():
+    """displacement.w travels to the consumer like in the reference's shaders (WaterSurfaceMesh.vert:29): the
+    vertex-stage kernel hands out the sampled Jacobian and the foam test of .frag:210-212 can be applied to it."""
+    from oracle import consumer as C
+    from watersurfacerendering_amd import _abi
+    n, lam = 256, -2.5
+    b = make_gpu(n, None, seed=77, lam=lam)
+    b.set_mode(_abi.OCEAN_MODE_JACOBIAN)
+    amp = float(b.compute_waves(1.0)[0])
+    disp, nrm = b.read_maps()
+    pos, nr = b.displace_grid(0, n, 1000.0 / 512.0, 1.0, lam)
+    opos, onr = C.displace_grid(disp[0], nrm[0], amp, n, 1000.0 / 512.0, 1.0, lam)
+    assert np.abs(pos - opos).max() <= 1e-6 * np.abs(opos).max()
+    foam, ofoam = C.foam_mask(pos), C.foam_mask(opos)
+    assert 0.0 < ofoam.mean() < 0.5
+    assert (foam != ofoam).mean() <= 1e-4            # only vertices whose w rounds differently around 0 may differ
     b.close()

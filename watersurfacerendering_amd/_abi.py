@@ -25,7 +25,7 @@ OCEAN_E_UNSUPPORTED = -6
 OCEAN_E_COMM = -7
 OCEAN_COMM_ID_BYTES = 128
 OCEAN_ALL_TILES = 0xFFFFFFFF
-OCEAN_MODE_FULL7, OCEAN_MODE_CHOPPY5, OCEAN_MODE_HEIGHT1 = 0, 1, 2
+OCEAN_MODE_FULL7, OCEAN_MODE_CHOPPY5, OCEAN_MODE_HEIGHT1, OCEAN_MODE_JACOBIAN = 0, 1, 2, 3
 
 #: every symbol include/ocean.h declares (tests check the .so exports each one)
 SYMBOLS = [

@@ -45,10 +45,10 @@ static void free_device(ocean_ctx* c)
 
 static void free_set(ocean_ctx* c, int i)
 {
-    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
+    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->jraw[i], c->jac0[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
     for (void* b : per) if (b) (void)hipFree(b);
     if (c->mm_host[i]) (void)hipHostFree(c->mm_host[i]);
-    c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->minmax[i] = nullptr;
+    c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->jraw[i] = nullptr; c->jac0[i] = nullptr; c->minmax[i] = nullptr;
     c->dispN[i] = nullptr; c->nrmN[i] = nullptr; c->mm_host[i] = nullptr;
 }
 
@@ -57,14 +57,18 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     const size_t nu = n / 2 + 1, nup = n / 2 + 8;
     // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
-    HIP_TRY(hipMalloc(&c->z[i], t * 3 * nu * 2 * nup * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->z[i], t * 4 * nu * 2 * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->hraw[i], t * nup * n * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->jraw[i], t * nup * n * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->jac0[i], t * nup * n * sizeof(float)));
     // zero-fill ON THE CHAIN'S OWN STREAM: the chain streams are non-blocking (no implicit ordering with the
     // null stream), and the first z pass of the chain is enqueued right behind this
-    HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
+    HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 4 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
     HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
     HIP_TRY(hipMemsetAsync(c->hraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
+    HIP_TRY(hipMemsetAsync(c->jraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
+    HIP_TRY(hipMemsetAsync(c->jac0[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
     HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
     // the displacement pass also drops the final min/max keys into this host-coherent buffer, so the
     // synchronous ComputeWaves needs one stream synchronisation and no device-to-host copy
@@ -325,7 +329,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         SYNC_ALL(c);
         for (int i = 0; i < MAXD; ++i)
             if (c->z[i]) {
-                HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
+                HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 4 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
                 HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
             }
         c->inter_bits_zeroed = c->inter_bits;
@@ -411,7 +415,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
-    a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
+    a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set]; a.minmax = c->minmax[set];
     a.minmax_host = c->mm_host[set];
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
@@ -725,7 +729,7 @@ int ocean_set_dispersion(ocean_t* c, int kind, float param)
 
 int ocean_set_mode(ocean_t* c, int mode)
 {
-    if (!c || mode < OCEAN_MODE_FULL7 || mode > OCEAN_MODE_HEIGHT1) return OCEAN_E_INVALID;
+    if (!c || mode < OCEAN_MODE_FULL7 || mode > OCEAN_MODE_JACOBIAN) return OCEAN_E_INVALID;
     c->mode = mode;                 // takes effect at the next frame, like SetLambda
     return OCEAN_OK;
 }
@@ -851,7 +855,8 @@ int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
     // 8 (h0) + 2 (16-bit dispersion; 4 when the fp32 array is needed) + 14 + 14 (half-size intermediates out and
     // in) + 2 + 2 (raw height) + 32 (maps).  SURVEY.md 8d's model of a plain 3.5-transform two-pass scheme is 108.
     if (!c) return 74;
-    return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0) - (c->inter_bits == 16 ? 14 : 0);
+    // OCEAN_MODE_JACOBIAN: the height plane becomes a full pair (+2 +2) and three more half-size real planes go out and in (+3*(2+2) - 4 for the hraw already counted) = +12
+    return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0) - (c->inter_bits == 16 ? 14 : 0) + (c->mode == OCEAN_MODE_JACOBIAN ? (c->inter_bits == 16 ? 10 : 12) : 0);
 }
 
 }  // extern "C"

@@ -47,6 +47,8 @@ struct ocean_ctx {
     float2* z[MAXD] = {};
     float2* zh[MAXD] = {};
     float* hraw[MAXD] = {};
+    float* jraw[MAXD] = {};        // OCEAN_MODE_JACOBIAN intermediates (allocated with the chain)
+    float* jac0[MAXD] = {};
     unsigned* minmax[MAXD] = {};
     unsigned* mm_host[MAXD] = {};   // pinned, device-visible copy of minmax written by the last kernel of a frame
     float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)

@@ -84,10 +84,10 @@ template <class T> __device__ __forceinline__ const T& at32(const T* base, unsig
 // half2, multiplied first by a per-tile power of two `scale` chosen at ocean_prepare from a time-independent bound
 // of the column sums so that nothing can overflow (k_inter_bounds); the same arrays, half the bytes (14 -> 7 B/texel
 // out of the z pass and into the x pass).  Stated accuracy of that mode: tests/test_parity_gpu.py.
-template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v, float scale = 1.0f)
+template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v, float scale = 1.0f, float scale_y = 0.0f)
 {
     if constexpr (Z16) {
-        const __half2 h = __floats2half2_rn(v.x * scale, v.y * scale);
+        const __half2 h = __floats2half2_rn(v.x * scale, v.y * (scale_y != 0.0f ? scale_y : scale));
         unsigned bits;
         __builtin_memcpy(&bits, &h, 4);
         unsigned* p = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(base) + idx * 4u);
@@ -102,14 +102,14 @@ template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(fl
     }
 }
 // element idx of an intermediate array as float2 (times `unscale` in the half2 form)
-template <bool Z16> __device__ __forceinline__ float2 load_z(const float2* base, unsigned idx, float unscale)
+template <bool Z16> __device__ __forceinline__ float2 load_z(const float2* base, unsigned idx, float unscale, float unscale_y = 0.0f)
 {
     if constexpr (Z16) {
         const unsigned bits = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(base) + idx * 4u);
         __half2 h;
         __builtin_memcpy(&h, &bits, 4);
         const float2 f = __half22float2(h);
-        return make_float2(f.x * unscale, f.y * unscale);
+        return make_float2(f.x * unscale, f.y * (unscale_y != 0.0f ? unscale_y : unscale));
     } else {
         return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + idx * 8u);
     }
@@ -141,11 +141,13 @@ struct FrameArgs {
     const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
     const float2* tw;        // [N]             exp(+2 pi i k / N)
-    float2* z;               // [tiles][3][N/2+1][2][NUP] row-transformed pairs: row m, side 0 = columns
+    float2* z;               // [tiles][4][N/2+1][2][NUP] row-transformed pairs (the 4th only in OCEAN_MODE_JACOBIAN): row m, side 0 = columns
                              //   u = 0..N/2, side 1 = columns (N-u)%N, NUP = N/2 + 8 (padded)
     float2* zh;              // [tiles][N/2+1][NUP]      row-transformed height, columns 0..N/2
     const float4* zscale;    // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k): powers of two of the half2 intermediates (Z16 kernels)
     float* hraw;             // [tiles][NUP][N]          signed raw height of map rows 0..N/2 (+ padding rows)
+    float* jraw;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: signed d(Dx)/dz = d(Dz)/dx of the same rows
+    float* jac0;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: (1 + lambda dDx/dx)(1 + lambda dDz/dz) of the same rows
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
     unsigned* minmax_host;   // [tiles][2]       host-coherent copy, written by the displacement pass
     float4* disp;            // [tiles][N][N]
@@ -154,7 +156,8 @@ struct FrameArgs {
     const float* lambda;     // [tiles], or null: every tile uses lambda_all
     float lambda_all;
     float t;
-    int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only)
+    int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only),
+                             // 3 JACOBIAN (FULL7 + the cross derivative; displacement.w = Jacobian of the horizontal displacement)
 };
 
 
@@ -400,7 +403,7 @@ template <int N> struct Half {
     static constexpr int NU = N / 2 + 1;          // columns (units) / rows kept: 0..N/2
     static constexpr int NUP = N / 2 + 8;         // padded to a multiple of 8
     static constexpr size_t Z_GROUP = (size_t)NU * 2 * NUP;       // float2 per packed pair
-    static constexpr size_t Z_TILE = 3 * Z_GROUP;
+    static constexpr size_t Z_TILE = 4 * Z_GROUP;                 // pairs 0..2, and pair 3 = (height, cross derivative) of OCEAN_MODE_JACOBIAN
     static constexpr size_t ZH_TILE = (size_t)NU * NUP;
     static constexpr size_t HRAW_TILE = (size_t)NUP * N;          // floats
 };
@@ -471,7 +474,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         OCEAN_STAMP(2);
     }
     // -- batch B: slot 0 = pair 2 (dDx/dx, dDz/dz), slot 1 = height ----------------
-    const float full7 = (a.mode == 0) ? 1.0f : 0.0f;
+    // OCEAN_MODE_JACOBIAN: slot 1 becomes pair 3 = (height, dDx/dz): the cross derivative's spectrum
+    // i kz * (-i ux) h~ = kz ux h~ = kx uz h~ (.cpp:330-335; both of the reference's extra fields are this one), even
+    // like the height, rides in the imaginary part the height transform leaves empty.  The result is then a full
+    // complex column (not conjugate-symmetric in p any more): stored like the other pairs, as z group 3.
+    const float full7 = (a.mode == 0 || a.mode == 3) ? 1.0f : 0.0f;
+    const bool jac = a.mode == 3;
     {
         auto in = [&](int e, int c, int, int) -> c32 {
             float sv, tx, tz;
@@ -483,15 +491,20 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             const float kz2 = kz * kz;
             const float d = kx2 + kz2;
             const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;
-            const float g = full7 * inv * sv;                      // pair 2 only exists in the 7-field mode
-            return make_float2(c ? sv : kx2 * g, c ? 0.0f : kz2 * g);
+            const float g = full7 * inv * sv;                      // pair 2 only exists in the 7-field modes
+            // cross derivative: kx kz / |k| is odd in kx and in kz separately, so on the self-mirrored Nyquist column
+            // (nb == 0) or row (e == 0) -- where one component of k(-idx) keeps its sign -- its Hermitian part takes
+            // S- instead of S+ (both at once: S+ again)
+            const float tc = COL0 ? (e == 0 ? sv : tx) : tz;
+            return make_float2(c ? sv : kx2 * g, c ? (jac ? kx * kz * inv * tc : 0.0f) : kz2 * g);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);     // real input: other half is the conjugate
+                if (jac) store_z<ZNT, Z16>(zt, (unsigned)(3 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, su, sk);
+                else if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);     // real input: other half is the conjugate
                 return;
             }
             store_z<ZNT, Z16>(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, sk);
@@ -629,16 +642,16 @@ template <int N> constexpr size_t zpass_lds_bytes()
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the
 // mirror image eps * Z(N-mf, N-u) = eps * side 1 of row N-mf.
 template <int N, bool Z16 = false>
-__device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, int mf, int u, float eps, float unscale = 1.0f)
+__device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, int mf, int u, float eps, float unscale = 1.0f, float unscale_y = 0.0f)
 {
     using HF = Half<N>;
 #ifdef OCEAN_ABL_NOLOAD
     return make_float2(1.0f + mf, 0.5f * u);
 #endif
-    if (mf <= N / 2) return load_z<Z16>(zg, (unsigned)(mf * 2 * HF::NUP + u), unscale);
+    if (mf <= N / 2) return load_z<Z16>(zg, (unsigned)(mf * 2 * HF::NUP + u), unscale, unscale_y);
     // mirror of the self-mirrored units 0 and N/2 is the unit itself (side 0)
     const int side = (u == 0 || u == N / 2) ? 0 : 1;
-    if constexpr (Z16) return load_z<true>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), eps * unscale);
+    if constexpr (Z16) return load_z<true>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), eps * unscale, eps * unscale_y);
     const c32 v = load_z<false>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), 1.0f);
     return make_float2(eps * v.x, eps * v.y);
 }
@@ -672,7 +685,7 @@ __device__ __forceinline__ void for_each_output(int tid, F f)
 // one height launch, then all three pairs per workgroup with register prefetch -- was
 // measured slower at every size and removed.)
 // ============================================================================
-template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -683,11 +696,52 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     constexpr int LM = 1;                                 // last-stage lane layout (fft_engine.h): a wave = one map row, 1 KiB bursts
     TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
-    constexpr int HB = HF::NUP / (2 * C);                 // height workgroups
     constexpr int NB = (HF::NU + C - 1) / C;              // normal workgroups
+    constexpr int HB = JAC ? NB : HF::NUP / (2 * C);      // height workgroups
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
 
-    if (blockIdx.x < HB) {
+    if constexpr (JAC) {
+        // ---- PAIR-3 workgroup (OCEAN_MODE_JACOBIAN): the height travels as the real part of pair 3 with the cross
+        // derivative as its imaginary part, so C rows per workgroup like every pair (not 2 C real rows): raw signed
+        // height and cross derivative of rows u0 .. u0+C-1 out (both even: the mirrored rows hold the same values),
+        // global min/max of the height.
+        if (blockIdx.x < HB) {
+            constexpr int NW = (T + 63) / 64;
+            float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
+            const int u0 = xcd_swizzle(blockIdx.x, HB) * C;
+            const float2* __restrict__ z3 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + ((size_t)tile * HF::Z_TILE + 3 * HF::Z_GROUP) * (Z16 ? 4 : 8));
+            float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
+            float* __restrict__ jraw = a.jraw + (size_t)tile * HF::HRAW_TILE;
+            [[maybe_unused]] float ux = 1.0f, uy = 1.0f;
+            if constexpr (Z16) { const float4 zs = a.zscale[tile]; ux = zs.z; uy = zs.w; }
+            float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
+            auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z3, nf, u0 + c, 1.0f, ux, uy); };
+            auto out = [&](int p, int c, c32 v, int, int) {
+                const int q = u0 + c;
+                if (q > N / 2) return;                                  // padding row
+                const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+                const float ha = s * v.x;
+                vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha);
+                at32(hraw, hraw_index(N, p, q)) = ha;
+                at32(jraw, hraw_index(N, p, q)) = s * v.y;
+            };
+            batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                vmin = fminf(vmin, __shfl_xor(vmin, o));
+                vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            }
+            if ((tid & 63) == 0) { red[tid >> 6] = vmin; red[NW + (tid >> 6)] = vmax; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; ++w) { vmin = fminf(vmin, red[w]); vmax = fmaxf(vmax, red[NW + w]); }
+                atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
+                atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
+            }
+            return;
+        }
+    }
+    if (!JAC && blockIdx.x < HB) {
         constexpr int NW = (T + 63) / 64;
         float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
         const int u0 = xcd_swizzle(blockIdx.x, HB) * 2 * C;
@@ -747,6 +801,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     const float2* __restrict__ z2 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(z1) + HF::Z_GROUP * ESN);
     [[maybe_unused]] const float uk = Z16 ? a.zscale[tile].w : 1.0f;
     float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
+    [[maybe_unused]] float* __restrict__ jac0 = JAC ? a.jac0 + (size_t)tile * HF::HRAW_TILE : nullptr;
+    [[maybe_unused]] const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
     c32 held[LS::IT][LS::RL];
     auto emit = [&](int p, int c, c32 slopes, c32 derivs) {
         const int q = u0 + c;
@@ -754,6 +810,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
         // (slope x, slope z, dDx/dx, dDz/dz) * sign   (.cpp:430-435)
         const float4 o = make_float4(s * slopes.x, s * slopes.y, s * derivs.x, s * derivs.y);
+        if constexpr (JAC)          // (1 + lambda s dxDx)(1 + lambda s dzDz) of .cpp:423-425, finished by the displacement pass
+            at32(jac0, hraw_index(N, p, q)) = (1.0f + lambda * o.z) * (1.0f + lambda * o.w);
         OCEAN_STORE(nrm, q * N + p, o);
         if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
             OCEAN_STORE(nrm, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, -o.y, o.z, o.w));
@@ -784,7 +842,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     if constexpr (PREFETCH) {
         c32 xa[FS::IT][FS::R0];
         fetch(z1, -1.0f, xa);
-        if (a.mode == 0) fetch(z2, 1.0f, xb);
+        if (a.mode != 1) fetch(z2, 1.0f, xb);
         auto in = [&](int, int, int u, int i) -> c32 { return xa[u][i]; };
         auto out = [&](int, int, c32 v, int u, int i) { held[u][i] = v; };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
@@ -811,7 +869,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     }
 }
 
-template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false>
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -830,6 +888,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
     float hv[LS::IT][LS::RL];
+    [[maybe_unused]] float jv[JAC ? LS::IT : 1][JAC ? LS::RL : 1], j0[JAC ? LS::IT : 1][JAC ? LS::RL : 1];
 #pragma unroll
     for (int u = 0; u < LS::IT; ++u) {
         const int w = tid + u * T;
@@ -837,7 +896,13 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
             int c, j;
             LS::map(w, c, j);
 #pragma unroll
-            for (int i = 0; i < LS::RL; ++i) hv[u][i] = at32(hraw, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+            for (int i = 0; i < LS::RL; ++i) {
+                hv[u][i] = at32(hraw, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                if constexpr (JAC) {
+                    jv[u][i] = at32(a.jraw + (size_t)tile * HF::HRAW_TILE, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                    j0[u][i] = at32(a.jac0 + (size_t)tile * HF::HRAW_TILE, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                }
+            }
         }
     }
     const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];
@@ -854,10 +919,15 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
         const int q = u0 + c;
         if (q > N / 2) return;
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, 1.0f);
+        float w = 1.0f;
+        if constexpr (JAC) {        // (1 + l s dxDx)(1 + l s dzDz) - (l s dxDz)(l s dzDx), .cpp:422-426 (the two cross terms are one field)
+            const float cross = lambda * jv[u][i];
+            w = j0[u][i] - cross * cross;
+        }
+        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, w);
         OCEAN_STORE(disp, q * N + p, o);
-        if (q != 0 && q != N / 2)
-            OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, 1.0f));
+        if (q != 0 && q != N / 2)       // mirror: the displacements are odd, height and Jacobian even
+            OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, w));
     };
     if (a.mode == 2) {               // HEIGHT1: no horizontal displacement, no transform
         for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });

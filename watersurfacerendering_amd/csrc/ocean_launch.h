@@ -47,14 +47,18 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         OCEAN_ALLOW_Z4(false, false) OCEAN_ALLOW_Z4(true, false) OCEAN_ALLOW_Z4(false, true) OCEAN_ALLOW_Z4(true, true)
 #undef OCEAN_ALLOW_Z4
 #undef OCEAN_ALLOW_Z
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, false>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, false>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, false, true>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_b<N, C, G::T_C, typename G::PC, true, true>, lds_b)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, false>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, false>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, false, true>, lds_m)) != hipSuccess) return e;
-        if ((e = allow_lds(k_xpass_disp<N, C, G::T_C, typename G::PC, true, true>, lds_m)) != hipSuccess) return e;
+#define OCEAN_ALLOW_X(kern, lds) \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, false, false, false>, lds)) != hipSuccess) return e; \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, true, false, false>, lds)) != hipSuccess) return e;  \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, false, true, false>, lds)) != hipSuccess) return e;  \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, true, true, false>, lds)) != hipSuccess) return e;   \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, false, false, true>, lds)) != hipSuccess) return e;  \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, true, false, true>, lds)) != hipSuccess) return e;   \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, false, true, true>, lds)) != hipSuccess) return e;   \
+        if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, true, true, true>, lds)) != hipSuccess) return e;
+        OCEAN_ALLOW_X(k_xpass_b, lds_b)
+        OCEAN_ALLOW_X(k_xpass_disp, lds_m)
+#undef OCEAN_ALLOW_X
         c->attr_n = (uint32_t)N;
     }
 #ifdef OCEAN_STAMPS
@@ -94,12 +98,16 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     arm(1);
 #endif
     {
-        const dim3 gb(hb_b + nb, tiles), gd(nb, tiles), blk(G::T_C);
+        const bool jac = a.mode == 3;       // OCEAN_MODE_JACOBIAN: the height role works on pair 3, C rows per workgroup
+        const dim3 gb((jac ? nb : hb_b) + nb, tiles), gd(nb, tiles), blk(G::T_C);
         hipEvent_t* mb = marks ? marks + 2 : nullptr;
         hipEvent_t* md = marks ? marks + 4 : nullptr;
+#define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16)                                                                \
+        do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, a);          \
+             else launch(kern<N, C, G::T_C, typename G::PC, nts, z16, false>, grid, blk, lds, st, ev, a); } while (0)
 #define OCEAN_XPASS(kern, grid, lds, ev, nts)                                                                       \
-        do { if (stream_maps & 8) launch(kern<N, C, G::T_C, typename G::PC, nts, true>, grid, blk, lds, st, ev, a);    \
-             else launch(kern<N, C, G::T_C, typename G::PC, nts, false>, grid, blk, lds, st, ev, a); } while (0)
+        do { if (stream_maps & 8) OCEAN_XPASS2(kern, grid, lds, ev, nts, true);                                       \
+             else OCEAN_XPASS2(kern, grid, lds, ev, nts, false); } while (0)
         if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true);
         else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false);
 #ifdef OCEAN_STAMPS
@@ -107,6 +115,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
         if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true);
         else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false);
+#undef OCEAN_XPASS2
 #undef OCEAN_XPASS
     }
     return hipGetLastError();
