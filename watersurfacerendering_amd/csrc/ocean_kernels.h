@@ -422,9 +422,20 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
 
 // The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
 // column nb == 0, the only one where Tx = S- along the whole column.
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16>
+// Interleaved transforms per z-pass batch: 2 (two batches: {pair 0, pair 1}, {pair 2, height}) or 4 (all of a
+// column's transforms in ONE batch with twice the threads).  Four at once halves the dependent chain of a
+// workgroup -- stages, barriers, LDS round trips -- which is what a single small tile waits for: 512^2 z pass
+// 8.0 -> 6.9 us.  At 1024^2 it is slower (14.9 -> 16.5 us) and from 2048 up the two-batch form keeps three
+// workgroups per CU.  (The same idea for the normal-map role -- pairs 1 and 2 as one batch of 2 C columns -- was
+// measured 50-60 % slower at both sizes; profiles/r02_small_tile_experiments.txt.)
+#ifndef OCEAN_ZC4
+#define OCEAN_ZC4 1
+#endif
+template <int N> constexpr int zpass_columns() { return (OCEAN_ZC4 && N == 512) ? 4 : 2; }
+
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
-                                                 const TwiddleRegs<N, 2, T, P>& twr, float kx, float sm0, int tid,
+                                                 const TwiddleRegs<N, ZC, T, P>& twr, float kx, float sm0, int tid,
                                                  int tile, int nb)
 {
     using HF = Half<N>;
@@ -448,6 +459,39 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             tz = (e == 0) ? sm0 : sv;
         }
     };
+    if constexpr (ZC == 4) {
+        // -- one batch: slot 0 = pair 0, slot 1 = pair 1, slot 2 = pair 2, slot 3 = height (or pair 3) ----------
+        const float full7 = (a.mode == 0 || a.mode == 3) ? 1.0f : 0.0f;
+        const float choppy = a.mode != 2 ? 1.0f : 0.0f;           // HEIGHT1 keeps only slot 3
+        const bool jac = a.mode == 3;
+        auto in = [&](int e, int c, int, int) -> c32 {
+            float sv, tx, tz;
+            fetch(e, sv, tx, tz);
+            const float kz = kzt[e];
+            const float d = kx2 + kz * kz;
+            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;      // |k| > 1e-5 (.h:135)
+            if (c < 2) {
+                const float f = (c ? -1.0f : inv) * choppy;        // pair 1: (-kz Tz, kx Tx); pair 0: (uz Tz, -ux Tx)
+                return make_float2(kz * f * tz, -kx * f * tx);
+            }
+            const float g = full7 * inv * sv;
+            const float tc = COL0 ? (e == 0 ? sv : tx) : tz;       // cross derivative: see the two-batch form below
+            return c == 2 ? make_float2(kx2 * g, kz * kz * g) : make_float2(sv, jac ? kx * kz * inv * tc : 0.0f);
+        };
+        auto out = [&](int p, int c, c32 v, int, int) {
+            const unsigned pos = (unsigned)(p <= N / 2 ? p : HF::NUP + (N - p));
+            if (c == 3) {
+                if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + pos, v, su, sk);
+                else if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);
+                return;
+            }
+            if (a.mode == 2) return;
+            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
+        };
+        batch_fft<N, 4, T, P>(fbuf, twr, tid, in, out);
+        OCEAN_STAMP(3);
+        return;
+    } else {
     // -- batch A: slot 0 = pair 0 (Dx, Dz), slot 1 = pair 1 (sx, sz) ------------
     if (a.mode != 2) {
         auto in = [&](int e, int c, int, int) -> c32 {
@@ -512,6 +556,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
     }
+    }
 }
 
 // ============================================================================
@@ -536,8 +581,9 @@ template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, b
 __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* fbuf = reinterpret_cast<c32*>(smem);                              // 2 interleaved transforms
-    float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());    // S+ [N]
+    constexpr int ZC = zpass_columns<N>();
+    c32* fbuf = reinterpret_cast<c32*>(smem);                              // ZC interleaved transforms
+    float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, ZC>());   // S+ [N]
     float* kzt = sp + N;                                                   // kz table [N]
     float* raw = reinterpret_cast<float*>(fbuf);                           // h~ columns nb, nbb (before the FFTs)
 
@@ -556,7 +602,7 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     [[maybe_unused]] const uint16_t* __restrict__ oq = a.omega_q + tile * n2;
 
     OCEAN_STAMP(0);
-    TwiddleRegs<N, 2, T, P> twr;
+    TwiddleRegs<N, ZC, T, P> twr;
     twr.load(a.tw, tid);
     // -- phase 1: animate columns nb and nbb; all loads issued before the first sincos
     {
@@ -629,13 +675,13 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     __syncthreads();
     OCEAN_STAMP(1);
 
-    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
-    else zpass_transforms<N, T, P, false, ZNT, Z16>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_transforms<N, T, P, false, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
 }
 
 template <int N> constexpr size_t zpass_lds_bytes()
 {
-    return sizeof(c32) * fft_lds_elems<N, 2>() + sizeof(float) * 2 * N;
+    return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * 2 * N;
 }
 
 // ---- x-pass helpers ------------------------------------------------------------------
@@ -1016,7 +1062,7 @@ OCEAN_GEO(32, 64, Plan<32>, 4, 64, Plan<32>)
 OCEAN_GEO(64, 64, Plan<64>, 4, 64, Plan<64>)
 OCEAN_GEO(128, 64, Plan<128>, 4, 64, Plan<128>)
 OCEAN_GEO(256, 64, Plan<256>, 4, 64, Plan<256>)
-OCEAN_GEO(512, 128, Plan<512>, 4, 256, Plan<512>)
+OCEAN_GEO(512, (zpass_columns<512>() == 4 ? 256 : 128), Plan<512>, 4, 256, Plan<512>)
 // from 1024 up the z pass runs radix-8 butterflies with twice the threads (one more LDS
 // exchange, about half the VGPRs): -9 % at 1024, -1.5 % at 2048, -4.5 % at 4096
 OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), 4, 256, Plan<1024>)
