@@ -545,6 +545,17 @@ const double* oracle_stage_ms(const oracle_ctx* c) { return c->stage_ms; }
  * intermediate checks: field f in [0,7): h, sx, sz, Dx, Dz, dxDx, dzDz.     */
 const float* oracle_field(const oracle_ctx* c, int f) { return (const float*)(c->ff + (size_t)f * c->n * c->n); }
 
+/* Team size of the following frames (bench.py looks for the fastest one for its strong CPU baseline: a container
+ * may expose more logical CPUs than its quota lets run at once). */
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

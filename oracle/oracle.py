@@ -71,6 +71,8 @@ def lib() -> C.CDLL:
         L.oracle_wind.argtypes = [P, C.POINTER(C.c_float)]
         L.oracle_gauss_pair.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.argtypes = [C.c_int]
+        L.oracle_set_num_threads.restype = None
         L.oracle_fftw_available.restype = C.c_int
         L.oracle_set_external_fft.argtypes = [P, FFT_CB, C.c_void_p]
         L.oracle_set_external_fft.restype = None

@@ -69,11 +69,20 @@ def traffic(path, n, tiles=1, fetch_factor=2.0):
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
         key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
-        out[key] = {"hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * fetch_factor + v["WRITE_SIZE"] * 1024),
-                    "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"], "fetch_factor": fetch_factor,
-                    "correction": f"FETCH_SIZE x {fetch_factor} (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md HBM "
-                                  "section, confirmed for these access widths by tools/ubench/fetchcal.hip, profiles/README.md); WRITE_SIZE as read",
-                    "source": rel(path) + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)"}
+        ent = {"hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * fetch_factor + v["WRITE_SIZE"] * 1024),
+               "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"], "fetch_factor": fetch_factor,
+               "source": rel(path) + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)"}
+        if k == "k_zpass":
+            ent["correction"] = (f"FETCH_SIZE x {fetch_factor}: its loads are coalesced (16 / 4 bytes per lane), for which "
+                                 "tools/ubench/fetchcal.hip measures known bytes / FETCH_SIZE = 2.000 (128-byte requests tallied at 64: "
+                                 "MI355X_MICROARCH.md HBM section; profiles/r02_fetch_calibration.txt); WRITE_SIZE as read")
+        else:       # the x passes gather 32-byte pieces: the request size of such reads is not observable
+            ent["hbm_bytes_per_launch_low"] = int(v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024)
+            ent["correction"] = (f"UPPER bound: FETCH_SIZE x {fetch_factor} as for coalesced reads.  These kernels read 32-byte pieces of "
+                                 "16.5 KB-strided rows; for that shape fetchcal measures FETCH_SIZE ALREADY 1.4-1.9 x the useful bytes (64-byte "
+                                 "requests for 32-byte pieces) and the counters cannot tell 64- from 128-byte requests, so the true figure "
+                                 "lies between hbm_bytes_per_launch_low (x 1) and this one (profiles/r02_fetch_calibration.txt); WRITE_SIZE as read")
+        out[key] = ent
     save("traffic.json", out)
 
 
