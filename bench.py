@@ -380,13 +380,24 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
     compute = timed(2, False, False)
     serial = timed(1, True, True)
     overlapped = timed(2, True, False)
+    # one more gathered frame, checked: the gather is a collective, so EVERY rank takes part; the root compares its own
+    # tiles in the receive buffer with its maps and one tile of the last rank with that rank's checksum
+    b.set_pipeline_depth(1)
+    b.compute_waves_async(1.0); b.gather_maps(0, *rp); b.synchronize()
+    import numpy as np
+    d, q = b.read_maps(tiles - 1, 1)
+    mine = torch.tensor([float(np.float64(d).sum()), float(np.float64(q).sum())], dtype=torch.float64, device=red_dev)
+    sums = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+    if world > 1:
+        dist.all_gather(sums, mine)
     ok = None
-    if rank == 0:                                            # the root's copy of its own tiles equals its maps
-        b.set_pipeline_depth(1)
-        b.compute_waves_async(1.0); b.gather_maps(0, *rp); b.synchronize()
-        import numpy as np
-        d, q = b.read_maps(0, 1)
-        ok = bool(np.array_equal(recv[0, 0, 0].cpu().numpy(), d[0]) and np.array_equal(recv[1, 0, 0].cpu().numpy(), q[0]))
+    if rank == 0:
+        d0, q0 = b.read_maps(0, 1)
+        ok = bool(np.array_equal(recv[0, 0, 0].cpu().numpy(), d0[0]) and np.array_equal(recv[1, 0, 0].cpu().numpy(), q0[0]))
+        last = world - 1
+        got = (float(recv[0, last, tiles - 1].double().sum()), float(recv[1, last, tiles - 1].double().sum()))
+        want = (float(sums[last][0]), float(sums[last][1]))
+        ok = ok and all(abs(g - w) <= 1e-6 * max(1.0, abs(w)) for g, w in zip(got, want))
     b.comm_destroy()
     b.close()
     per_rank = tiles * n * n * 4 * 4 * 2
