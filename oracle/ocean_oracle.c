@@ -123,7 +123,8 @@ typedef struct oracle_ctx {
     cpx_d* fd;               /* 7*n*n, only for ORACLE_FFT_F64 */
     cpx_f* work_f;           /* 7 * 17n */
     cpx_d* work_d;
-    cpx_f* work_team;        /* threads * 17n, ORACLE_FFT_F32_TEAM */
+    cpx_f* work_team;        /* work_team_threads * 17n, ORACLE_FFT_F32_TEAM */
+    int work_team_threads;
     void* fftw_plans[9];     /* ORACLE_FFT_FFTW: one in-place plan per field, like WSTessendorf.cpp:191-232 */
     oracle_fft_cb ext_fft;   /* ORACLE_FFT_EXTERNAL */
     void* ext_fft_user;
@@ -380,8 +381,10 @@ float oracle_compute_waves(oracle_ctx* c, float t, int mode, int fft_kind)
         if (!c->fd || !c->work_d) return NAN;
     }
 
-    if (fft_kind == ORACLE_FFT_F32_TEAM && !c->work_team) {
-        c->work_team = (cpx_f*)malloc((size_t)oracle_num_threads() * 17 * n * sizeof(cpx_f));
+    if (fft_kind == ORACLE_FFT_F32_TEAM && (!c->work_team || c->work_team_threads < oracle_num_threads())) {
+        free(c->work_team);                  /* the team size may have grown since (oracle_set_num_threads) */
+        c->work_team_threads = oracle_num_threads();
+        c->work_team = (cpx_f*)malloc((size_t)c->work_team_threads * 17 * n * sizeof(cpx_f));
         if (!c->work_team) return NAN;
     }
     if (fft_kind == ORACLE_FFT_FFTW) {

@@ -23,7 +23,7 @@ def _env():
     return env
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_rccl_gather_of_sharded_tiles(world):
     if _gpus() < world:
         pytest.skip(f"needs {world} GPUs, node has {_gpus()}")
