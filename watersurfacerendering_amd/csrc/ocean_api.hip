@@ -336,7 +336,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     }
     if (c->inter_bits == 16) {
         if (!c->zscale) {
-            HIP_TRY(hipMalloc(&c->zscale, t * sizeof(float4)));
+            HIP_TRY(hipMalloc(&c->zscale, 2 * t * sizeof(float4)));
             HIP_TRY(hipMalloc(&c->zbounds, t * 2 * sizeof(unsigned)));
         }
         HIP_TRY(hipMemsetAsync(c->zbounds, 0, t * 2 * sizeof(unsigned), stream_of(c, 0)));
@@ -345,21 +345,29 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         HIP_TRY(hipStreamSynchronize(stream_of(c, 0)));
         std::vector<unsigned> hb(2 * t);
         HIP_TRY(hipMemcpy(hb.data(), c->zbounds, 2 * t * sizeof(unsigned), hipMemcpyDeviceToHost));
-        std::vector<float4> zs(t);
+        std::vector<float4> zs(2 * t);
+        auto pow2_below = [](float x) {          // largest power of two <= x (x > 0)
+            int e = 0;
+            (void)std::frexp(x, &e);             // x = f * 2^e, f in [0.5, 1)
+            return std::ldexp(1.0f, e - 1);
+        };
         for (size_t i = 0; i < t; ++i) {
-            float sc[2];
-            for (int k = 0; k < 2; ++k) {
-                float b; std::memcpy(&b, &hb[2 * i + k], 4);
-                // a component of a z-pass output is bounded by 2 * (column sum + mirrored column sum) <= 4 * max column
-                // sum; the largest finite half is 65504: scale = the largest power of two with 4 * b * scale <= 32768
-                const float bound = 4.0f * b;
-                int e = 0;
-                if (bound > 0.0f && std::isfinite(bound)) (void)std::frexp(bound, &e);     // bound = f * 2^e, f in [0.5, 1)
-                sc[k] = bound > 0.0f ? std::ldexp(1.0f, 15 - e) : 1.0f;
-            }
-            zs[i] = make_float4(sc[0], sc[1], 1.0f / sc[0], 1.0f / sc[1]);
+            float b[2];
+            for (int k = 0; k < 2; ++k) std::memcpy(&b[k], &hb[2 * i + k], 4);
+            // a component of a z-pass output is bounded by 2 * (column sum + mirrored column sum) <= 4 * max column
+            // sum (of |h0| for the pairs weighted by unit vectors, of |k||h0| for those weighted by k); the largest
+            // finite half is 65504: scale = the largest power of two with 4 * bound * scale <= 32768
+            auto scale_for = [&](float bound4) { return (bound4 > 0.0f && std::isfinite(bound4)) ? pow2_below(32768.0f / bound4) : 1.0f; };
+            const float su = scale_for(4.0f * b[0]), sk = scale_for(4.0f * b[1]);
+            // pair 3 (Jacobian mode) packs the height with the k-weighted cross derivative; after ONE axis both parts of
+            // the transform hold a mixture of the two, so they share one scale, and the cross part is first amplified by
+            // a power of two g to the height's magnitude so that it keeps its relative precision
+            const float g = (b[0] > 0.0f && b[1] > 0.0f && std::isfinite(b[0] / b[1])) ? pow2_below(b[0] / b[1]) : 1.0f;
+            const float s3 = scale_for(4.0f * (b[0] + g * b[1]));
+            zs[2 * i] = make_float4(su, sk, 1.0f / su, 1.0f / sk);
+            zs[2 * i + 1] = make_float4(s3, g, 1.0f / s3, 1.0f / g);
         }
-        HIP_TRY(hipMemcpy(c->zscale, zs.data(), t * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->zscale, zs.data(), 2 * t * sizeof(float4), hipMemcpyHostToDevice));
     }
     SYNC_ALL(c);
     {

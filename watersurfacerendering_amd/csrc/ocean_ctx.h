@@ -63,7 +63,7 @@ struct ocean_ctx {
     int mode = 0;                  // OCEAN_MODE_*
     int inter_bits_zeroed = 32;    // layout the intermediates' padding was last zero-filled for
     int inter_bits = 32;           // 32, or 16: the z-pass outputs (z, zh) are stored as scaled half2 (ocean_set_intermediate_precision)
-    float4* zscale = nullptr;      // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k)
+    float4* zscale = nullptr;      // [tiles][2]: (s_u, s_k, 1/s_u, 1/s_k), (s_3, g, 1/s_3, 1/g) -- FrameArgs::zscale
     unsigned* zbounds = nullptr;   // [tiles][2] float bits of the column-sum bounds (k_inter_bounds)
     int h0_bits = 32;              // 32, or 16: frames read a scaled half2 copy of h0
     __half2* h0h = nullptr;

@@ -144,7 +144,9 @@ struct FrameArgs {
     float2* z;               // [tiles][4][N/2+1][2][NUP] row-transformed pairs (the 4th only in OCEAN_MODE_JACOBIAN): row m, side 0 = columns
                              //   u = 0..N/2, side 1 = columns (N-u)%N, NUP = N/2 + 8 (padded)
     float2* zh;              // [tiles][N/2+1][NUP]      row-transformed height, columns 0..N/2
-    const float4* zscale;    // [tiles] (scale_u, scale_k, 1/scale_u, 1/scale_k): powers of two of the half2 intermediates (Z16 kernels)
+    const float4* zscale;    // [tiles][2] powers of two of the half2 intermediates (Z16 kernels): [0] = (s_u, s_k, 1/s_u, 1/s_k) for the pairs
+                             //   weighted by unit vectors / by k; [1] = (s_3, g, 1/s_3, 1/g) for pair 3 of the Jacobian mode, whose
+                             //   cross-derivative part is first multiplied by g so that both parts have the height's magnitude
     float* hraw;             // [tiles][NUP][N]          signed raw height of map rows 0..N/2 (+ padding rows)
     float* jraw;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: signed d(Dx)/dz = d(Dz)/dx of the same rows
     float* jac0;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: (1 + lambda dDx/dx)(1 + lambda dDz/dz) of the same rows
@@ -441,7 +443,8 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     using HF = Half<N>;
     const float kx2 = kx * kx;
     [[maybe_unused]] float su = 1.0f, sk = 1.0f;              // half2 intermediates: pair 0 and the height scale with su, pairs 1 and 2 with sk
-    if constexpr (Z16) { const float4 zs = a.zscale[tile]; su = zs.x; sk = zs.y; }
+    [[maybe_unused]] float s3 = 1.0f, g3 = 1.0f;              // pair 3 (Jacobian mode): common scale of both parts, gain of the cross derivative
+    if constexpr (Z16) { const float4 zs = a.zscale[2 * tile]; su = zs.x; sk = zs.y; const float4 z3 = a.zscale[2 * tile + 1]; s3 = z3.x; g3 = z3.y; }
     // element offsets; the half2 form packs the same elements at 4 bytes each from the same base address
     constexpr size_t ES = Z16 ? 4 : 8;
     float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + ((size_t)tile * HF::Z_TILE + (size_t)nb * 2 * HF::NUP) * ES);
@@ -476,12 +479,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             }
             const float g = full7 * inv * sv;
             const float tc = COL0 ? (e == 0 ? sv : tx) : tz;       // cross derivative: see the two-batch form below
-            return c == 2 ? make_float2(kx2 * g, kz * kz * g) : make_float2(sv, jac ? kx * kz * inv * tc : 0.0f);
+            return c == 2 ? make_float2(kx2 * g, kz * kz * g) : make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
             const unsigned pos = (unsigned)(p <= N / 2 ? p : HF::NUP + (N - p));
             if (c == 3) {
-                if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + pos, v, su, sk);
+                if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + pos, v, s3);
                 else if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);
                 return;
             }
@@ -540,14 +543,14 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             // (nb == 0) or row (e == 0) -- where one component of k(-idx) keeps its sign -- its Hermitian part takes
             // S- instead of S+ (both at once: S+ again)
             const float tc = COL0 ? (e == 0 ? sv : tx) : tz;
-            return make_float2(c ? sv : kx2 * g, c ? (jac ? kx * kz * inv * tc : 0.0f) : kz2 * g);
+            return make_float2(c ? sv : kx2 * g, c ? (jac ? g3 * (kx * kz * inv * tc) : 0.0f) : kz2 * g);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16>(zt, (unsigned)(3 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, su, sk);
+                if (jac) store_z<ZNT, Z16>(zt, (unsigned)(3 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, s3);
                 else if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);     // real input: other half is the conjugate
                 return;
             }
@@ -759,7 +762,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
             float* __restrict__ jraw = a.jraw + (size_t)tile * HF::HRAW_TILE;
             [[maybe_unused]] float ux = 1.0f, uy = 1.0f;
-            if constexpr (Z16) { const float4 zs = a.zscale[tile]; ux = zs.z; uy = zs.w; }
+            [[maybe_unused]] float ig = 1.0f;                   // the cross derivative went in amplified by g (zscale): out comes g times it
+            if constexpr (Z16) { const float4 z3 = a.zscale[2 * tile + 1]; ux = z3.z; uy = z3.z; ig = z3.w; }
             float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
             auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z3, nf, u0 + c, 1.0f, ux, uy); };
             auto out = [&](int p, int c, c32 v, int, int) {
@@ -769,7 +773,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
                 const float ha = s * v.x;
                 vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha);
                 at32(hraw, hraw_index(N, p, q)) = ha;
-                at32(jraw, hraw_index(N, p, q)) = s * v.y;
+                at32(jraw, hraw_index(N, p, q)) = Z16 ? s * v.y * ig : s * v.y;
             };
             batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 #pragma unroll
@@ -795,7 +799,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         const float2* __restrict__ zh = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
         float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
         float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
-        [[maybe_unused]] const float uu = Z16 ? a.zscale[tile].z : 1.0f;
+        [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
         auto in = [&](int nf, int c, int, int) -> c32 {
             const int row = nf <= N / 2 ? nf : N - nf;
             float4 z;
@@ -845,7 +849,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     constexpr size_t ESN = Z16 ? 4 : 8;
     const float2* __restrict__ z1 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + ((size_t)tile * HF::Z_TILE + HF::Z_GROUP) * ESN);
     const float2* __restrict__ z2 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(z1) + HF::Z_GROUP * ESN);
-    [[maybe_unused]] const float uk = Z16 ? a.zscale[tile].w : 1.0f;
+    [[maybe_unused]] const float uk = Z16 ? a.zscale[2 * tile].w : 1.0f;
     float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
     [[maybe_unused]] float* __restrict__ jac0 = JAC ? a.jac0 + (size_t)tile * HF::HRAW_TILE : nullptr;
     [[maybe_unused]] const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
@@ -928,7 +932,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     constexpr int NB = (HF::NU + C - 1) / C;
     const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
     const float2* __restrict__ z0 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + (size_t)tile * HF::Z_TILE * (Z16 ? 4 : 8));
-    [[maybe_unused]] const float uu = Z16 ? a.zscale[tile].z : 1.0f;
+    [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
     float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
     TwiddleRegs<N, C, T, P, LM> twr;
