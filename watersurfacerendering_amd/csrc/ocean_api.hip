@@ -334,7 +334,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
             }
         c->inter_bits_zeroed = c->inter_bits;
     }
-    if (c->inter_bits == 16) {
+    {   // scales of the half2 intermediates and the gain of the Jacobian mode's cross derivative (both precisions)
         if (!c->zscale) {
             HIP_TRY(hipMalloc(&c->zscale, 2 * t * sizeof(float4)));
             HIP_TRY(hipMalloc(&c->zbounds, t * 2 * sizeof(unsigned)));

@@ -444,7 +444,11 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     const float kx2 = kx * kx;
     [[maybe_unused]] float su = 1.0f, sk = 1.0f;              // half2 intermediates: pair 0 and the height scale with su, pairs 1 and 2 with sk
     [[maybe_unused]] float s3 = 1.0f, g3 = 1.0f;              // pair 3 (Jacobian mode): common scale of both parts, gain of the cross derivative
-    if constexpr (Z16) { const float4 zs = a.zscale[2 * tile]; su = zs.x; sk = zs.y; const float4 z3 = a.zscale[2 * tile + 1]; s3 = z3.x; g3 = z3.y; }
+    if constexpr (Z16) { const float4 zs = a.zscale[2 * tile]; su = zs.x; sk = zs.y; s3 = a.zscale[2 * tile + 1].x; }
+    // the cross derivative goes in multiplied by a power of two g that brings it to the height's magnitude (in fp32 as
+    // well: packed with a height a thousand times its size it would inherit the height's rounding error) and comes out
+    // of the x pass divided by it
+    if (a.mode == 3) g3 = a.zscale[2 * tile + 1].y;
     // element offsets; the half2 form packs the same elements at 4 bytes each from the same base address
     constexpr size_t ES = Z16 ? 4 : 8;
     float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + ((size_t)tile * HF::Z_TILE + (size_t)nb * 2 * HF::NUP) * ES);
@@ -762,8 +766,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
             float* __restrict__ jraw = a.jraw + (size_t)tile * HF::HRAW_TILE;
             [[maybe_unused]] float ux = 1.0f, uy = 1.0f;
-            [[maybe_unused]] float ig = 1.0f;                   // the cross derivative went in amplified by g (zscale): out comes g times it
-            if constexpr (Z16) { const float4 z3 = a.zscale[2 * tile + 1]; ux = z3.z; uy = z3.z; ig = z3.w; }
+            float ig = 1.0f;                                    // the cross derivative went in amplified by g (zscale): out comes g times it
+            { const float4 z3 = a.zscale[2 * tile + 1]; ig = z3.w; if constexpr (Z16) { ux = z3.z; uy = z3.z; } }
             float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
             auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z3, nf, u0 + c, 1.0f, ux, uy); };
             auto out = [&](int p, int c, c32 v, int, int) {
@@ -773,7 +777,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
                 const float ha = s * v.x;
                 vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha);
                 at32(hraw, hraw_index(N, p, q)) = ha;
-                at32(jraw, hraw_index(N, p, q)) = Z16 ? s * v.y * ig : s * v.y;
+                at32(jraw, hraw_index(N, p, q)) = s * v.y * ig;
             };
             batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
 #pragma unroll
