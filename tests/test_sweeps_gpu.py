@@ -95,3 +95,37 @@ def test_every_mode_precision_depth_combination_on_one_context():
             f.compute_waves(1.7); d2, q2 = f.read_maps(); f.close()
             assert np.array_equal(d, d2) and np.array_equal(q, q2), (n, tiles, bits, mode, depth)
         b.close()
+
+
+def test_batch_with_different_parameters_per_tile_and_resizes():
+    """A batch whose tiles differ in EVERY parameter (tile length, wind, Phillips constant, damping, lambda, time offset)
+    equals single-tile contexts with the same parameters bit for bit, in the fp32, half2 and Jacobian forms; and a context
+    keeps its mode / precision / depth settings across SetTileSize."""
+    import watersurfacerendering_amd as W
+    rng = np.random.default_rng(11)
+    n, tiles, seed = 128, 4, 900
+    per = [dict(tile_length=float(rng.choice([120.0, 1000.0, 3000.0])), wind_dir_x=float(rng.uniform(-1, 1)), wind_dir_y=float(rng.uniform(0.1, 1)),
+                wind_speed=float(rng.uniform(3, 50)), phillips_const=float(10 ** rng.uniform(-8, -6)), damping=float(rng.uniform(0, 0.5)),
+                lambda_=float(rng.uniform(-2.5, -0.3))) for _ in range(tiles)]
+    offs = np.array([0.0, -1.5, 40.0, 1234.5], np.float32)
+    for bits, mode in ((32, 0), (16, 0), (32, 3), (16, 3)):
+        b = W.OceanBatch(n, tiles, 0)
+        for i, p in enumerate(per):
+            b.set_params(tile=i, **p)
+        b.set_intermediate_precision(bits); b.set_mode(mode); b.set_time_offsets(offs)
+        b.prepare(seed)
+        amps = b.compute_waves(2.0)
+        d, q = b.read_maps()
+        for i, p in enumerate(per):
+            s = W.OceanBatch(n, 1, 0); s.set_params(**p); s.set_intermediate_precision(bits); s.set_mode(mode); s.prepare(seed + i)
+            a1 = s.compute_waves(float(np.float32(2.0) + offs[i])); d1, q1 = s.read_maps(); s.close()
+            assert np.array_equal(d[i], d1[0]) and np.array_equal(q[i], q1[0]) and amps[i] == a1[0], (bits, mode, i)
+        # resize: settings survive, results equal a fresh context of the new size
+        b.set_tile_size(64)
+        b.prepare(seed)
+        b.compute_waves(2.0)
+        d64, q64 = b.read_maps(tiles - 1, 1)
+        f = W.OceanBatch(64, 1, 0); f.set_params(**per[-1]); f.set_intermediate_precision(bits); f.set_mode(mode); f.prepare(seed + tiles - 1)
+        f.compute_waves(float(np.float32(2.0) + offs[-1])); df, qf = f.read_maps(); f.close()
+        assert np.array_equal(d64, df) and np.array_equal(q64, qf), (bits, mode, "after resize")
+        b.close()

@@ -266,6 +266,8 @@ int ocean_set_tile_size(ocean_t* c, uint32_t tile_size)
     int rc = alloc_device(c);
     if (rc) return rc;
     c->lambda_dirty = true;
+    if (c->use_toff)        // the per-tile time offsets are a property of the context, not of the buffers just re-created
+        HIP_TRY(hipMemcpy(c->toff, c->toff_host.data(), c->tiles * sizeof(float), hipMemcpyHostToDevice));
     return OCEAN_OK;
 }
 
@@ -524,8 +526,9 @@ int ocean_set_time_offsets(ocean_t* c, const float* offsets)
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
-    if (!offsets) { c->use_toff = false; return OCEAN_OK; }
-    HIP_TRY(hipMemcpy(c->toff, offsets, c->tiles * sizeof(float), hipMemcpyHostToDevice));
+    if (!offsets) { c->use_toff = false; c->toff_host.clear(); return OCEAN_OK; }
+    c->toff_host.assign(offsets, offsets + c->tiles);
+    HIP_TRY(hipMemcpy(c->toff, c->toff_host.data(), c->tiles * sizeof(float), hipMemcpyHostToDevice));
     c->use_toff = true;
     return OCEAN_OK;
 }

@@ -57,6 +57,7 @@ struct ocean_ctx {
     float4* ext_nrm = nullptr;
     float* toff = nullptr;
     bool use_toff = false;
+    std::vector<float> toff_host;   // the per-tile time offsets as set by the caller (re-uploaded when the device buffers are re-created)
     float* lambda = nullptr;
     ocean::TileParams* tparams = nullptr;
     float2* xi = nullptr;          // injected or generated draws (kept for read-back)
