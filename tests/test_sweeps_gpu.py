@@ -81,19 +81,21 @@ def test_half2_intermediates_sweep_against_the_fp32_path():
 
 def test_every_mode_precision_depth_combination_on_one_context():
     import watersurfacerendering_amd as W
-    for n, tiles in [(64, 5), (512, 2)]:
+    for n, tiles, period in [(64, 5, 200.0), (512, 2, 200.0), (64, 2, 4.0e5)]:     # the last: dispersion multiples beyond 16 bits (fp32 omega variants)
         b = W.OceanBatch(n, tiles, 0)
-        for bits, mode, depth in itertools.product((32, 16, 32), (0, 3, 1, 2, 0), (1, 3)):
-            b.set_intermediate_precision(bits); b.set_mode(mode); b.set_pipeline_depth(depth)
+        b.set_params(anim_period=period)
+        for (bits, hbits), mode, depth in itertools.product(((32, 32), (16, 32), (16, 16), (32, 16), (32, 32)), (0, 3, 1, 2, 0), (1, 3)):
+            b.set_intermediate_precision(bits); b.set_spectrum_precision(hbits); b.set_mode(mode); b.set_pipeline_depth(depth)
             b.prepare(123)
             for j in range(4):
                 b.compute_waves_async(0.2 * j)
             b.compute_waves_async(1.7); b.synchronize()
             d, q = b.read_maps(tiles - 1, 1)
-            assert np.all(np.isfinite(d)) and np.all(np.isfinite(q)), (n, bits, mode, depth)
-            f = W.OceanBatch(n, 1, 0); f.set_intermediate_precision(bits); f.set_mode(mode); f.prepare(123 + tiles - 1)
+            assert np.all(np.isfinite(d)) and np.all(np.isfinite(q)), (n, period, bits, hbits, mode, depth)
+            f = W.OceanBatch(n, 1, 0); f.set_params(anim_period=period); f.set_intermediate_precision(bits); f.set_spectrum_precision(hbits)
+            f.set_mode(mode); f.prepare(123 + tiles - 1)
             f.compute_waves(1.7); d2, q2 = f.read_maps(); f.close()
-            assert np.array_equal(d, d2) and np.array_equal(q, q2), (n, tiles, bits, mode, depth)
+            assert np.array_equal(d, d2) and np.array_equal(q, q2), (n, tiles, period, bits, hbits, mode, depth)
         b.close()
 
 
