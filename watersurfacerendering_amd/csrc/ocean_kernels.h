@@ -28,8 +28,10 @@
 //
 // HBM bytes per texel actually moved (this pipeline): 10 (h0 8, dispersion as a 16-bit multiple
 // of the base frequency 2) + 14 + 14 (half-size intermediates out and in) + 2 + 2 (raw height)
-// + 32 (maps) = 74, against 108 for the straightforward 3.5-transform two-pass scheme the
-// roofline accounting of SURVEY.md section 8d assumes.
+// + 32 (maps) = 74, against 108 for the straightforward 3.5-transform two-pass scheme SURVEY.md
+// section 8d models.  60 with half2 intermediates (Z16 kernels), 86 in the Jacobian mode (JAC kernels:
+// the height plane becomes pair 3 = (height, cross derivative), and two more half-size real planes
+// carry the Jacobian's factors to the displacement pass).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
