@@ -300,3 +300,38 @@ def test_bench_self_launcher_starts_n_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["roofline"]["frac"] < 1.0 and out["roofline"]["frame_frac"] < 1.0
+
+
+def test_readout_paths_under_pipelining_refer_to_the_last_frame():
+    """ocean_read_maps, ocean_read_maps_async, ocean_read_maps_staging, ocean_device_maps and the vertex-stage consumer
+    all refer to the frame enqueued LAST, whatever chain it ran on (depth 3, 1..5 frames in flight)."""
+    import watersurfacerendering_amd as W
+    n = 256
+    ref = make_batch(n, seed=321)
+    b = make_batch(n, seed=321, depth=3)
+    pinned = np.zeros((2, n, n, 4), dtype=np.float32)
+    staging = np.zeros(48 + 2 * n * n * 16, dtype=np.uint8)
+    W.host_register(pinned); W.host_register(staging)
+    try:
+        for frames in (1, 2, 3, 4, 5):
+            times = [0.11 * (frames * 10 + j) for j in range(frames)]
+            for t in times:
+                b.compute_waves_async(t)
+            b.read_maps_async(pinned[0:1], pinned[1:2])             # enqueued behind the last frame, no host wait
+            b.read_maps_staging(staging, 30, 10)                     # maps at align16(40) = 48
+            pos, _ = b.displace_grid(0, 64)                          # synchronises
+            b.synchronize()
+            ref.compute_waves(times[-1])
+            d, q = ref.read_maps()
+            d2, q2 = b.read_maps()
+            assert np.array_equal(d, d2) and np.array_equal(q, q2), frames
+            assert np.array_equal(pinned[0], d[0]) and np.array_equal(pinned[1], q[0]), frames
+            assert np.array_equal(staging[48:48 + n * n * 16].view(np.float32).reshape(n, n, 4), d[0])
+            assert np.array_equal(staging[48 + n * n * 16:].view(np.float32).reshape(n, n, 4), q[0])
+            rpos, _ = ref.displace_grid(0, 64)
+            assert np.array_equal(pos, rpos), frames
+            pd, pq = b.device_maps()                                 # zero-copy pointers of that same frame's maps
+            assert pd and pq and pd != pq
+    finally:
+        W.host_unregister(pinned); W.host_unregister(staging)
+    ref.close(); b.close()
