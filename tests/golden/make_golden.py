@@ -10,6 +10,7 @@ unpinned").
     python tests/golden/make_golden.py
 
 ocean_n*.npz: xi (n,n,2) f32 input draws, params, per t: amp, min, max, disp, nrm (f32).
+jacobian_n*.npz: displacement.w of OCEAN_MODE_JACOBIAN for the same inputs (per t: w (n,n) f32).
 sampled_n*.npz (n = 256, 512, 1024): seed, per t: amp, min, max, per-channel mean and max of
 |value|, and 1024 texels sampled by a fixed LCG (index list included).
 """
@@ -89,6 +90,26 @@ def sampled():
         print("wrote", f"sampled_n{n}_default.npz")
 
 
+def jacobian():
+    """OCEAN_MODE_JACOBIAN: displacement.w = the Jacobian of the horizontal displacement, per the
+    intent of WSTessendorf.cpp:330-335,421-428, for the inputs of the ocean_n*.npz fixtures (same seeds and parameters)."""
+    for n in (16, 32, 64):
+        for name, kw in CASES.items():
+            seed = 0x5EED0000 + n
+            xi = O.gauss_xi_numpy(seed, n)
+            kw2 = dict(kw)
+            length = kw2.pop("length", 1000.0)
+            o = O.Oracle(n, length, **kw2)
+            o.prepare(xi=xi)
+            out = {"seed": np.uint64(seed), "n": np.int32(n), "times": np.array(TIMES, np.float32), "inputs": f"ocean_n{n}_{name}.npz"}
+            for i, t in enumerate(TIMES):
+                _, d, _ = o.compute_waves(t, mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+                out[f"w{i}"] = d[..., 3].astype(np.float32)
+            np.savez_compressed(os.path.join(HERE, f"jacobian_n{n}_{name}.npz"), **out)
+            print("wrote", f"jacobian_n{n}_{name}.npz")
+
+
 if __name__ == "__main__":
     main()
     sampled()
+    jacobian()

@@ -272,3 +272,22 @@ def test_foam_mask_follows_the_fragment_stage():
         pos, _ = C.displace_grid(d, q, a, n, 1000.0 / 512.0, 1.0, lam)
         frac.append(float(C.foam_mask(pos).mean()))
     assert frac[0] <= frac[1] <= frac[2] and frac[2] > 0.0 and frac[0] < 0.01
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "jacobian_n*.npz"))))
+def test_jacobian_golden_fixtures(path):
+    """Committed displacement.w of OCEAN_MODE_JACOBIAN for the inputs of the ocean_n*.npz fixtures: the C oracle reproduces
+    it, and so does the independent numpy restatement."""
+    g = np.load(path)
+    base = np.load(os.path.join(GOLDEN, str(g["inputs"])))
+    n = int(g["n"])
+    kw = dict(wind=tuple(base["wind"]), wind_speed=float(base["wind_speed"]), lam=float(base["lam"]))
+    o = O.Oracle(n, float(base["length"]), **kw)
+    o.prepare(xi=base["xi"])
+    prep = O.numpy_prepare(n, base["xi"], length=float(base["length"]), wind=kw["wind"], wind_speed=kw["wind_speed"])
+    for i, t in enumerate(g["times"]):
+        _, d, _ = o.compute_waves(float(t), mode=O.MODE_JACOBIAN, fft=O.FFT_F64)
+        w = g[f"w{i}"]
+        assert np.abs(d[..., 3] - w).max() <= 2e-6 * np.abs(w).max()
+        _, dn, _, _, _ = O.numpy_compute_waves(prep, float(t), lam=kw["lam"], jacobian=True)
+        assert np.abs(dn[..., 3] - w).max() <= 1e-5 * np.abs(w).max()

@@ -714,3 +714,24 @@ def test_jacobian_with_half2_intermediates_cannot_overflow(n, seed):
             assert abs(ag - ao) <= Z16_TOL * ao
             assert max(chan_err(d[0], do)) <= Z16_TOL and max(chan_err(q[0], no)) <= Z16_TOL, (n, seed, t, chan_err(d[0], do))
         b.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "jacobian_n*.npz"))))
+def test_jacobian_golden_fixtures_on_gpu(path):
+    g = np.load(path)
+    base = np.load(os.path.join(GOLDEN, str(g["inputs"])))
+    from watersurfacerendering_amd import _abi
+    n = int(g["n"])
+    b = make_gpu(n, base["xi"][None], length=float(base["length"]), wind=tuple(map(float, base["wind"])),
+                 wind_speed=float(base["wind_speed"]), lam=float(base["lam"]))
+    b.set_mode(_abi.OCEAN_MODE_JACOBIAN)
+    for i, t in enumerate(g["times"]):
+        b.compute_waves(float(t))
+        d, q = b.read_maps()
+        w = g[f"w{i}"]
+        assert np.abs(d[0][..., 3] - w).max() <= TOL * np.abs(w).max()
+        for c in range(3):
+            m = max(float(np.abs(base[f"disp{i}"][..., c]).max()), 1e-30)
+            assert float(np.abs(d[0][..., c] - base[f"disp{i}"][..., c]).max()) <= TOL * m
+        assert max(chan_err(q[0], base[f"nrm{i}"])) <= TOL          # the seven reference fields are the FULL7 fixture's
+    b.close()
