@@ -178,6 +178,7 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
     ocean_ctx* c = new (std::nothrow) ocean_ctx();
     if (!c) return OCEAN_E_NOMEM;
     c->n = tile_size; c->tiles = tiles; c->device = device;
+    c->cu_count = prop.multiProcessorCount;
     c->params.resize(tiles);
     for (auto& p : c->params) ocean_default_params(&p);
     int rc = OCEAN_OK;
@@ -458,8 +459,10 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         const double resident = texels * (10.0 + (c->inter_bits == 16 ? 8.0 : 16.0) * (pipe ? c->depth : 1));
         if (resident > 300.0e6) stream_maps |= 4;
     }
+    static const char* const split_env = getenv("OCEAN_ZSPLIT");                // developer override (A/B runs): 0 = never split
+    if (!pipe && !(split_env && atoi(split_env) == 0)) stream_maps |= 16;       // this frame has the device to itself
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs): bit mask
-    if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 8);
+    if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 24);
     hipError_t e = hipErrorInvalidValue;
     if (c->n <= 256) e = ocean_launch_frame_small(c, a, stream_maps, st, marks);
     else if (c->n <= 1024) e = ocean_launch_frame_mid(c, a, stream_maps, st, marks);

@@ -29,6 +29,7 @@ struct ocean_ctx {
     int dispersion = 0;             // ocean_set_dispersion
     float dispersion_param = 0.0f;
     int last_set = 0;
+    int cu_count = 0;               // compute units of the device
     uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
     bool lambda_uniform = true;
     bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)
@@ -92,7 +93,8 @@ inline hipStream_t stream_of(const ocean_ctx* c, int set) { return c->user ? c->
 
 // One frame = three launches on `st` (ocean_launch.h); one entry point per group of tile sizes, each compiled in its
 // own translation unit (frames_*.hip) so that the library builds in parallel.  stream_maps: bit 0 normal map and
-// bit 1 displacement map stored non-temporally, bit 2 intermediates stored non-temporally, bit 3 half2 intermediates.
+// bit 1 displacement map stored non-temporally, bit 2 intermediates stored non-temporally, bit 3 half2 intermediates,
+// bit 4 the frame runs alone on the device (serial frames: the z pass may split its last round of columns).
 // marks: 6 events (start, stop per kernel) or null.
 hipError_t ocean_launch_frame_small(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);   // 16 .. 256
 hipError_t ocean_launch_frame_mid(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);     // 512, 1024

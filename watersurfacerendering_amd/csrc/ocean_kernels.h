@@ -160,6 +160,8 @@ struct FrameArgs {
     const float* lambda;     // [tiles], or null: every tile uses lambda_all
     float lambda_all;
     float t;
+    int zfull;               // z pass: workgroups [0, zfull) transform a whole spectrum column; the columns beyond are split over two
+                             //   workgroups each (one per batch of transforms) -- see k_zpass
     int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only),
                              // 3 JACOBIAN (FULL7 + the cross derivative; displacement.w = Jacobian of the horizontal displacement)
 };
@@ -440,7 +442,7 @@ template <int N> constexpr int zpass_columns() { return (OCEAN_ZC4 && N == 512) 
 template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
                                                  const TwiddleRegs<N, ZC, T, P>& twr, float kx, float sm0, int tid,
-                                                 int tile, int nb)
+                                                 int tile, int nb, int batches /* bit 0: {pair 0, pair 1}, bit 1: {pair 2, height} */)
 {
     using HF = Half<N>;
     const float kx2 = kx * kx;
@@ -502,7 +504,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         return;
     } else {
     // -- batch A: slot 0 = pair 0 (Dx, Dz), slot 1 = pair 1 (sx, sz) ------------
-    if (a.mode != 2) {
+    if (a.mode != 2 && (batches & 1)) {
         auto in = [&](int e, int c, int, int) -> c32 {
             float sv, tx, tz;
             fetch(e, sv, tx, tz);
@@ -533,7 +535,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     // complex column (not conjugate-symmetric in p any more): stored like the other pairs, as z group 3.
     const float full7 = (a.mode == 0 || a.mode == 3) ? 1.0f : 0.0f;
     const bool jac = a.mode == 3;
-    {
+    if (batches & 2) {
         auto in = [&](int e, int c, int, int) -> c32 {
             float sv, tx, tz;
             fetch(e, sv, tx, tz);
@@ -598,7 +600,11 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    const int nb = blockIdx.x;
+    // Serial frames of a tile whose columns do not fill the chip in whole rounds (2048^2: 1025 columns on 768 resident
+    // workgroups) end with a round of lone workgroups, each a long dependent chain: the host then splits the columns of
+    // that last round over two workgroups each, one per batch of transforms (both animate the column; a.zfull < N/2+1).
+    int nb = (int)blockIdx.x, batches = 3;
+    if (ZC == 2 && nb >= a.zfull) { const int r = nb - a.zfull; nb = a.zfull + (r >> 1); batches = 1 + (r & 1); }
     const int nbb = (N - nb) & (N - 1);
     const size_t n2 = (size_t)N * N;
     const float2* __restrict__ h0 = a.h0 + tile * n2;
@@ -684,8 +690,18 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     __syncthreads();
     OCEAN_STAMP(1);
 
-    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
-    else zpass_transforms<N, T, P, false, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb);
+    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
+    else zpass_transforms<N, T, P, false, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
+}
+
+// resident z-pass workgroups per CU (lower bound from LDS, threads and the register cap of the launch bounds)
+template <int N, int T> constexpr int zpass_blocks_per_cu()
+{
+    constexpr int by_lds = (int)(163840 / (sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * 2 * N));
+    constexpr int by_threads = 2048 / T;
+    constexpr int by_regs = (zpass_min_waves<N>() * 4 * 64) / T;
+    constexpr int m = by_lds < by_threads ? by_lds : by_threads;
+    return (by_regs >= 1 && by_regs < m) ? by_regs : (m < 1 ? 1 : m);
 }
 
 template <int N> constexpr size_t zpass_lds_bytes()

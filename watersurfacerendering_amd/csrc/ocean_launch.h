@@ -73,13 +73,21 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
     {
         unsigned gx = N / 2 + 1;
+        FrameArgs za = a;
+        za.zfull = (int)gx;
+        if ((stream_maps & 16) && tiles == 1 && zpass_columns<N>() == 2) {
+            // serial frames: split the columns of the last, partially filled round over two workgroups each
+            const unsigned slots = (unsigned)zpass_blocks_per_cu<N, G::T_ROWS>() * (unsigned)c->cu_count;
+            const unsigned rest = gx % slots;
+            if (gx > slots && rest != 0 && 2 * rest <= slots) { za.zfull = (int)(gx - rest); gx = (gx - rest) + 2 * rest; }
+        }
 #ifdef OCEAN_STAMPS
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
 #define OCEAN_ZPASS(h16, w16, znt) \
-        do { if (stream_maps & 8) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, true>, grid, block, lds_rows, st, marks, a); \
-             else launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, false>, grid, block, lds_rows, st, marks, a); } while (0)
+        do { if (stream_maps & 8) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, true>, grid, block, lds_rows, st, marks, za); \
+             else launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, false>, grid, block, lds_rows, st, marks, za); } while (0)
         const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
         switch (variant) {
             case 0: OCEAN_ZPASS(false, false, false); break;
