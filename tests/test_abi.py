@@ -164,3 +164,18 @@ def test_missing_extension_fails_loudly():
     env = dict(os.environ, OCEAN_HIP_LIB="/nonexistent/libocean_hip.so")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
     assert "LOUD" in r.stdout and "no CPU fallback" in r.stdout.replace("There is no CPU fallback", "no CPU fallback")
+
+
+def test_cpp_gather_host_builds_and_fails_loudly_without_a_gpu(abi, tmp_path):
+    """tests/cpp/gather_demo.cpp (the multi-GPU batch mode from a plain C++ host) must compile and link against the C ABI on
+    every CPU run; without a GPU it exits non-zero with the library's error text, no silent fallback."""
+    exe = tmp_path / "gather_demo"
+    lib_dir = os.path.dirname(abi.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cpp", "gather_demo.cpp"), "-o", str(exe),
+                    "-L", lib_dir, "-locean_hip", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe), "1", "64", "2", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "GATHER_OK" not in r.stdout
+        assert "RCCL error" in r.stderr or "no usable HIP device" in r.stderr

@@ -47,3 +47,25 @@ def test_bench_two_gpus_over_rccl():
     g = out["gather"]
     assert g["ranks"] == 2 and g["root_copy_matches_local_maps"] is True
     assert g["compute_only"]["tiles_per_s"] > g["compute_plus_gather_serial"]["tiles_per_s"] > 0
+
+
+def _build_gather_demo(tmp_path):
+    from watersurfacerendering_amd import _abi
+    exe = tmp_path / "gather_demo"
+    lib_dir = os.path.dirname(_abi.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cpp", "gather_demo.cpp"), "-o", str(exe),
+                    "-L", lib_dir, "-locean_hip", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 8])
+def test_cpp_host_shards_tiles_and_gathers_over_rccl(ranks, tmp_path):
+    """tests/cpp/gather_demo.cpp: the batch mode from a plain C++ host through the C ABI -- one forked process per GPU,
+    the RCCL id through pipes, the gather overlapped with the next batch; every rank's tiles verified on the root."""
+    if _gpus() < ranks:
+        pytest.skip(f"needs {ranks} GPUs, node has {_gpus()}")
+    exe = _build_gather_demo(tmp_path)
+    r = subprocess.run([str(exe), str(ranks), "256", "3", "6"], capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    assert f"GATHER_OK ranks {ranks} tiles {3 * ranks}" in r.stdout
