@@ -378,18 +378,21 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
         recv = torch.empty((2, world, tiles, n, n, 4), dtype=torch.float32, device=dev)
     rp = (recv[0].data_ptr(), recv[1].data_ptr()) if rank == 0 else (None, None)
 
-    def timed(depth, with_gather, sync_each):
+    recv16 = torch.empty((2, world, tiles, n, n, 4), dtype=torch.float16, device=dev) if rank == 0 else None
+    rp16 = (recv16[0].data_ptr(), recv16[1].data_ptr()) if rank == 0 else (None, None)
+
+    def timed(depth, with_gather, sync_each, half=False):
         b.set_pipeline_depth(depth)
         for j in range(5):                                   # warm-up (also first touch of every chain's buffers)
             b.compute_waves_async(DT * j)
             if with_gather:
-                b.gather_maps(0, *rp)
+                b.gather_maps(0, *(rp16 if half else rp), half=half)
         b.synchronize(); barrier()
         t0 = time.perf_counter()
         for j in range(reps):
             b.compute_waves_async(DT * j)
             if with_gather:
-                b.gather_maps(0, *rp)
+                b.gather_maps(0, *(rp16 if half else rp), half=half)
             if sync_each:
                 b.synchronize()
         b.synchronize(); barrier()
@@ -398,6 +401,7 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
     compute = timed(2, False, False)
     serial = timed(1, True, True)
     overlapped = timed(2, True, False)
+    overlapped16 = timed(2, True, False, half=True)
     # one more gathered frame, checked: the gather is a collective, so EVERY rank takes part; the root compares its own
     # tiles in the receive buffer with its maps and one tile of the last rank with that rank's checksum
     b.set_pipeline_depth(1)
@@ -429,6 +433,8 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
             "compute_only": {"ms_per_step": compute * 1e3, "tiles_per_s": total / compute},
             "compute_plus_gather_serial": {"ms_per_step": serial * 1e3, "tiles_per_s": total / serial},
             "compute_gather_overlapped": {"ms_per_step": overlapped * 1e3, "tiles_per_s": total / overlapped},
+            "compute_gather_overlapped_half_maps": {"ms_per_step": overlapped16 * 1e3, "tiles_per_s": total / overlapped16,
+                                                    "what": "ocean_gather_maps_f16: maps converted to IEEE half on the sender, 16 B/texel on the wire"},
             "root_ingest_GBps_overlapped": per_rank * (world - 1) / overlapped * 1e-9,
             "root_copy_matches_local_maps": ok}
 

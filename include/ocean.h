@@ -261,6 +261,10 @@ int ocean_comm_unique_id(void* id_out /* OCEAN_COMM_ID_BYTES */);
 int ocean_comm_init(ocean_t* ctx, int nranks, int rank, const void* id /* OCEAN_COMM_ID_BYTES */);
 int ocean_comm_destroy(ocean_t* ctx);
 int ocean_gather_maps(ocean_t* ctx, int root, void* d_recv_disp, void* d_recv_nrm);
+/* The same gather with the maps converted to IEEE half on the sending GPU first (round to nearest; 16 instead of 32
+ * bytes per texel over xGMI, SURVEY.md 8e's option): the root receives tiles*N*N*4 halves per map and rank.  For
+ * consumers that take half textures; the fp32 maps of the context are untouched.                                   */
+int ocean_gather_maps_f16(ocean_t* ctx, int root, void* d_recv_disp, void* d_recv_nrm);
 /* ncclResult_t of the most recent failing RCCL call on this thread (0 if none).                 */
 int ocean_last_rccl_error(void);
 

@@ -80,6 +80,7 @@ def test_argument_checking_without_device(abi):
     assert L.ocean_comm_init(None, 1, 0, None) == abi.OCEAN_E_INVALID
     assert L.ocean_comm_destroy(None) == abi.OCEAN_E_INVALID
     assert L.ocean_gather_maps(None, 0, None, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_gather_maps_f16(None, 0, None, None) == abi.OCEAN_E_INVALID
     L.ocean_destroy(None)
 
 

@@ -261,6 +261,16 @@ def test_native_rccl_gather_single_rank_and_staging_layout():
         ref.close()
     with pytest.raises(W.OceanError):
         b.gather_maps(1, None, None)                            # root out of range
+    # the same gather at half the bytes: the root receives exactly the maps rounded to IEEE half
+    recv16 = torch.zeros((2, 1, tiles, n, n, 4), dtype=torch.float16, device="cuda:0")
+    b.set_pipeline_depth(2)
+    for j in range(3):
+        b.compute_waves_async(0.3 * j)
+        b.gather_maps(0, recv16[0].data_ptr(), recv16[1].data_ptr(), half=True)
+    b.synchronize()
+    d, q = b.read_maps()
+    got16 = recv16.cpu().numpy()
+    assert np.array_equal(got16[0, 0], d.astype(np.float16)) and np.array_equal(got16[1, 0], q.astype(np.float16))
     b.comm_destroy()
     # staging layout, odd mesh sizes so that the pad matters
     vb, ib = 1000 * 32 + 4, 2998 * 4

@@ -160,10 +160,12 @@ class OceanBatch:
     def comm_destroy(self):
         _abi.check(self._L.ocean_comm_destroy(self._h), "ocean_comm_destroy")
 
-    def gather_maps(self, root: int, recv_disp: int | None, recv_nrm: int | None):
+    def gather_maps(self, root: int, recv_disp: int | None, recv_nrm: int | None, half: bool = False):
         """Enqueue the RCCL gather of the last enqueued frame's maps to `root` (device pointers of the receive
-        arrays [nranks][tiles][N][N][4] on the root, None elsewhere); asynchronous, see ocean.h."""
-        _abi.check(self._L.ocean_gather_maps(self._h, root, C.c_void_p(recv_disp), C.c_void_p(recv_nrm)), "ocean_gather_maps")
+        arrays [nranks][tiles][N][N][4] on the root, None elsewhere); asynchronous, see ocean.h.  half=True sends
+        the maps as IEEE halves (receive arrays of float16)."""
+        fn = self._L.ocean_gather_maps_f16 if half else self._L.ocean_gather_maps
+        _abi.check(fn(self._h, root, C.c_void_p(recv_disp), C.c_void_p(recv_nrm)), "ocean_gather_maps")
 
     def device_maps(self):
         d, q = C.c_void_p(), C.c_void_p()

@@ -48,6 +48,7 @@ static void free_set(ocean_ctx* c, int i)
     void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->jraw[i], c->jac0[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
     for (void* b : per) if (b) (void)hipFree(b);
     if (c->mm_host[i]) (void)hipHostFree(c->mm_host[i]);
+    for (auto& p : c->pack_half[i]) if (p) { (void)hipFree(p); p = nullptr; }
     c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->jraw[i] = nullptr; c->jac0[i] = nullptr; c->minmax[i] = nullptr;
     c->dispN[i] = nullptr; c->nrmN[i] = nullptr; c->mm_host[i] = nullptr;
 }
@@ -971,7 +972,7 @@ int ocean_comm_destroy(ocean_t* c)
     return OCEAN_OK;
 }
 
-int ocean_gather_maps(ocean_t* c, int root, void* d_recv_disp, void* d_recv_nrm)
+static int gather_impl(ocean_ctx* c, int root, void* d_recv_disp, void* d_recv_nrm, bool half)
 {
     if (!c) return OCEAN_E_INVALID;
     if (!c->comm) return OCEAN_E_NOT_READY;
@@ -980,22 +981,35 @@ int ocean_gather_maps(ocean_t* c, int root, void* d_recv_disp, void* d_recv_nrm)
     if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     const int set = c->last_set;
-    const size_t count = (size_t)c->tiles * c->n * c->n * 4;                 // floats per map array per rank
-    const float4* d = c->ext_disp ? c->ext_disp : c->dispN[set];
-    const float4* q = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
+    const size_t texels = (size_t)c->tiles * c->n * c->n;
+    const size_t count = texels * 4;                                          // elements per map array per rank
+    const void* d = c->ext_disp ? c->ext_disp : c->dispN[set];
+    const void* q = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
+    if (half) {     // convert on the frame's own stream, behind the frame: 16 instead of 32 bytes per texel on the wire
+        for (auto& p : c->pack_half[set]) if (!p) HIP_TRY(hipMalloc(&p, texels * sizeof(uint2)));
+        const unsigned blocks = (unsigned)((texels + 255) / 256 < 65535 ? (texels + 255) / 256 : 65535);
+        hipLaunchKernelGGL(k_pack_half, dim3(blocks), dim3(256), 0, stream_of(c, set), (const float4*)d, c->pack_half[set][0], texels);
+        hipLaunchKernelGGL(k_pack_half, dim3(blocks), dim3(256), 0, stream_of(c, set), (const float4*)q, c->pack_half[set][1], texels);
+        HIP_TRY(hipGetLastError());
+        d = c->pack_half[set][0]; q = c->pack_half[set][1];
+    }
     // order the gather behind the frame that wrote these maps, on the communication stream: the chains keep
     // synthesising meanwhile (at depth >= 2 the next frames write other map sets), and this chain's next frame
     // waits for gather_done before it rewrites the maps (enqueue_frame)
     HIP_TRY(hipEventRecord(c->frame_done[set], stream_of(c, set)));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->frame_done[set], 0));
+    const ncclDataType_t ty = half ? ncclHalf : ncclFloat;
     RCCL_TRY(rccl().GroupStart());
-    ncclResult_t r1 = rccl().Gather(d, d_recv_disp, count, ncclFloat, root, c->comm, c->comm_stream);   // zero-copy from the map buffers
-    ncclResult_t r2 = rccl().Gather(q, d_recv_nrm, count, ncclFloat, root, c->comm, c->comm_stream);
+    ncclResult_t r1 = rccl().Gather(d, d_recv_disp, count, ty, root, c->comm, c->comm_stream);   // zero-copy from the map buffers
+    ncclResult_t r2 = rccl().Gather(q, d_recv_nrm, count, ty, root, c->comm, c->comm_stream);
     RCCL_TRY(rccl().GroupEnd());
     RCCL_TRY(r1); RCCL_TRY(r2);
     HIP_TRY(hipEventRecord(c->gather_done[set], c->comm_stream));
     c->gather_pending[set] = true;
     return OCEAN_OK;
 }
+
+int ocean_gather_maps(ocean_t* c, int root, void* d_recv_disp, void* d_recv_nrm) { return gather_impl(c, root, d_recv_disp, d_recv_nrm, false); }
+int ocean_gather_maps_f16(ocean_t* c, int root, void* d_recv_disp, void* d_recv_nrm) { return gather_impl(c, root, d_recv_disp, d_recv_nrm, true); }
 
 }  // extern "C"

@@ -85,7 +85,8 @@ struct ocean_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t frame_done[MAXD] = {};   // recorded on a chain's stream behind the frame whose maps are gathered
     hipEvent_t gather_done[MAXD] = {};  // recorded on the communication stream behind that gather
-    bool gather_pending[MAXD] = {};     // the chain's next frame must wait for gather_done before rewriting the maps
+    bool gather_pending[MAXD] = {};
+    uint2* pack_half[MAXD][2] = {};    // half-precision copies of a chain's two maps for ocean_gather_maps_f16 (allocated on first use)     // the chain's next frame must wait for gather_done before rewriting the maps
 };
 
 

@@ -1009,6 +1009,20 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 }
 
 #ifdef OCEAN_INIT_KERNELS
+// Packed-map gather at half the bytes (the gather is xGMI-bound): one RGBA32F texel -> four halves
+// (round to nearest even; |values| of both maps are far below the largest half, 65504, for any sea the reference
+// parameters can describe -- larger values saturate to +-inf like any float -> half conversion).
+__global__ void k_pack_half(const float4* __restrict__ src, uint2* __restrict__ dst, size_t texels)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+        uint2 o;
+        __builtin_memcpy(&o.x, &a, 4); __builtin_memcpy(&o.y, &b, 4);
+        dst[i] = o;
+    }
+}
+
 // ============================================================================
 // Vertex-stage consumer: what the reference's vertex shader does with
 // the two maps (src/shaders/WaterSurfaceMesh.vert:24-41) for the grid its mesh generator
