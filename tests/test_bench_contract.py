@@ -94,3 +94,32 @@ def test_world_size_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "n_gpus" not in r.stdout and "refusing" in r.stderr
+
+
+def test_committed_bench_line_is_reproducible_from_profiles(bench):
+    """The roofline fractions of the committed default bench line (profiles/r02r_bench_default.json) can be recomputed from
+    the committed rocprofv3 summary (profiles/kernel_stats.json <- r02r_kernel_stats_2048_bench_depth1.csv) and the byte
+    accounting of this file: every kernel within 6 %, nothing above 1, and the summaries regenerate from the CSV."""
+    prof = os.path.join(ROOT, "profiles")
+    line = [l for l in open(os.path.join(prof, "r02r_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    st = json.load(open(os.path.join(prof, "kernel_stats.json")))
+    r = d["roofline"]
+    n2 = 2048 * 2048
+    assert d["config"]["tile_size"] == 2048 and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    for k, b in bench.KERNEL_BYTES_ACTUAL.items():
+        frac_from_rocprof = b * n2 / (st[k + "@2048"]["avg_us"] * 1e-6) * 1e-9 / bench.HBM_PEAK_GBPS
+        assert abs(r["kernels"][k]["frac"] - frac_from_rocprof) <= 0.06 * frac_from_rocprof, (k, r["kernels"][k]["frac"], frac_from_rocprof)
+        assert r["kernels"][k]["frac"] < 1.0
+    assert r["frac"] == r["kernels"][r["kernel"]]["frac"] and r["frame_frac"] < 1.0 and r["serial_frame_frac"] < 1.0
+    assert abs(r["frame_frac"] - bench.FRAME_BYTES_ACTUAL * n2 / (d["ms_per_step"] * 1e-3) * 1e-9 / bench.HBM_PEAK_GBPS) < 1e-9
+    # the summary itself regenerates from the committed CSV
+    import csv
+    import re
+    acc = {}
+    for row in csv.DictReader(open(os.path.join(prof, "r02r_kernel_stats_2048_bench_depth1.csv"))):
+        m = re.search(r"(k_[a-z_]+)<2048", row["Name"])
+        if m and m.group(1) in bench.KERNEL_BYTES_ACTUAL:
+            a = acc.setdefault(m.group(1), [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
+    for k, (calls, total) in acc.items():
+        assert abs(total / calls * 1e-3 - st[k + "@2048"]["avg_us"]) < 1e-6
