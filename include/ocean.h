@@ -227,6 +227,15 @@ int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 .. 8 */);
  * them out (synchronises), ocean_device_grid hands out the pointers.                  */
 int ocean_displace_grid(ocean_t* ctx, uint32_t tile, uint32_t grid_size, float vertex_distance,
                         float uv_scale, float choppy);
+/* Cascades (the reference's to-do "Endless - solving the tiling artifacts", README.md:37-44): the
+ * tiles first_tile .. first_tile+count-1 of the batch (count <= 8) -- independent oceans with their own tile length,
+ * wind, seed -- are summed by the consumer, tile c sampled at uv * uv_scales[c]:
+ *   position = inPos + sum_c (D_c.x, D_c.y * A_c, D_c.z),  w = min_c D_c.w
+ *   normal   = normalize(-S.x / (1 + choppy*S.z), 1, -S.y / (1 + choppy*S.w)),  S = sum_c normal-map sample of tile c
+ * With incommensurate scales the surface no longer repeats with the period of one tile.  Same output buffers
+ * and read-out as ocean_displace_grid.                                                                          */
+int ocean_displace_grid_cascades(ocean_t* ctx, uint32_t first_tile, uint32_t count, uint32_t grid_size,
+                                 float vertex_distance, const float* uv_scales /* count */, float choppy);
 int ocean_read_grid(ocean_t* ctx, float* positions, float* normals);
 int ocean_device_grid(ocean_t* ctx, void** d_positions, void** d_normals, uint32_t* vertices);
 

@@ -57,3 +57,30 @@ def foam_mask(positions: np.ndarray) -> np.ndarray:
     `if (inPos.w < 0.0) color = vec3(1.0)`): per VERTEX here, True where the surface folds over itself -- the
     Jacobian of the horizontal displacement, carried in displacement.w (WaterSurfaceMesh.vert:29), is negative."""
     return positions[:, 3] < F(0.0)
+
+
+def displace_grid_cascades(disps, nrms, amps, uv_scales, grid: int, vertex_distance: float, choppy: float = -1.0):
+    """Cascades (the reference's to-do "Endless - solving the tiling artifacts", README.md:37-44): the sum of
+    several independent tiles, tile c sampled at uv * uv_scales[c]; heights times their own amplitude, slopes and displacement
+    derivatives summed before the reference's normal formula (.vert:34-38); w = the smallest Jacobian slot."""
+    side, half = grid + 1, grid // 2
+    i = np.arange(side * side)
+    xi, yi = i % side - half, i // side - half
+    px = xi.astype(np.float32) * F(vertex_distance)
+    pz = yi.astype(np.float32) * F(vertex_distance)
+    u = (xi + half).astype(np.float32) / F(grid)
+    v = (yi + half).astype(np.float32) / F(grid)
+    dx = np.zeros(side * side, np.float32); dy = dx.copy(); dz = dx.copy()
+    s = np.zeros((side * side, 4), np.float32)
+    w = np.full(side * side, np.finfo(np.float32).max, np.float32)
+    for d, q, amp, sc in zip(disps, nrms, amps, uv_scales):
+        us, vs = u * F(sc), v * F(sc)
+        sd = sample_linear_repeat(np.ascontiguousarray(d, dtype=np.float32), us, vs)
+        dx = dx + sd[:, 0]; dy = dy + sd[:, 1] * F(amp); dz = dz + sd[:, 2]
+        w = np.minimum(w, sd[:, 3])
+        s = s + sample_linear_repeat(np.ascontiguousarray(q, dtype=np.float32), us, vs)
+    pos = np.stack([px + dx, F(0.0) + dy, pz + dz, w], axis=1).astype(np.float32)
+    nx = -(s[:, 0] / (F(1.0) + F(choppy) * s[:, 2]))
+    nz = -(s[:, 1] / (F(1.0) + F(choppy) * s[:, 3]))
+    ln = np.sqrt(nx * nx + F(1.0) + nz * nz)
+    return pos, np.stack([nx / ln, F(1.0) / ln, nz / ln, np.zeros_like(nx)], axis=1).astype(np.float32)

@@ -62,6 +62,7 @@ def test_argument_checking_without_device(abi):
     assert L.ocean_create(C.byref(h), 16, 65536, 0) == abi.OCEAN_E_UNSUPPORTED    # tiles index blockIdx.y
     assert L.ocean_displace_grid(None, 0, 16, 1.0, 1.0, -1.0) == abi.OCEAN_E_INVALID
     assert L.ocean_read_grid(None, None, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_displace_grid_cascades(None, 0, 1, 16, 1.0, None, -1.0) == abi.OCEAN_E_INVALID
     assert L.ocean_compute_waves(None, 0.0, None) == abi.OCEAN_E_INVALID
     assert L.ocean_prepare(None, 0, None) == abi.OCEAN_E_INVALID
     assert L.ocean_tile_size(None) == 0

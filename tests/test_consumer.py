@@ -89,3 +89,52 @@ def test_displace_grid_argument_checks_and_batches():
     p1, _ = b.displace_grid(1, 64)
     assert not np.array_equal(p0, p1)               # tiles have their own seed
     b.close()
+
+
+def test_oracle_cascades_reduce_to_one_tile_and_break_the_tile_period():
+    """oracle/consumer.py: one cascade = the plain vertex stage; a single tile sampled over two periods repeats exactly, the
+    sum of tiles at incommensurate rates does not (the reference's to-do "solving the tiling artifacts", README.md:37-44)."""
+    from oracle import consumer as C
+    n = 32
+    d0, q0 = _maps(n, 1); d1, q1 = _maps(n, 2)
+    p1, n1 = C.displace_grid(d0, q0, 3.0, 64, 1.0, 2.0, -1.0)
+    pc, nc = C.displace_grid_cascades([d0], [q0], [3.0], [2.0], 64, 1.0, -1.0)
+    assert np.array_equal(p1, pc) and np.array_equal(n1, nc)
+    side = 65
+    y = p1[:, 1].reshape(side, side)
+    assert np.allclose(y[:, :32], y[:, 32:64], atol=1e-5)                          # uv scale 2: the tile repeats after half the grid
+    pc2, _ = C.displace_grid_cascades([d0, d1], [q0, q1], [3.0, 2.0], [2.0, 2.0 * 1.37], 64, 1.0, -1.0)
+    y2 = pc2[:, 1].reshape(side, side)
+    assert np.abs(y2[:, :32] - y2[:, 32:64]).max() > 0.5
+
+
+@pytest.mark.gpu
+def test_cascade_consumer_matches_oracle_on_tiles_of_different_length():
+    """ocean_displace_grid_cascades on a batch whose tiles are cascades of one ocean (tile lengths 1000 / 370 / 93 m, own seeds):
+    against oracle/consumer.py, equal to ocean_displace_grid for a single cascade, and no longer periodic with the base tile."""
+    import watersurfacerendering_amd as W
+    from oracle import consumer as C
+    n, grid = 256, 512
+    lengths = [1000.0, 370.0, 93.0]
+    b = W.OceanBatch(n, len(lengths), 0)
+    for i, L in enumerate(lengths):
+        b.set_params(tile=i, tile_length=L)
+    b.prepare(0x5EED0000)
+    amps = b.compute_waves(2.75)
+    disp, nrm = b.read_maps()
+    scales = [2.0 * lengths[0] / L for L in lengths]              # the grid spans two base tiles; every cascade keeps its metres per texel
+    vd = 2.0 * lengths[0] / grid
+    pos, nr = b.displace_grid_cascades(scales, 0, grid, vd, -1.0)
+    opos, onr = C.displace_grid_cascades(disp, nrm, [float(a) for a in amps], scales, grid, vd, -1.0)
+    assert np.abs(pos - opos).max() <= 2e-6 * np.abs(opos).max()
+    assert np.abs(nr - onr).max() <= 4e-6
+    p1, n1 = b.displace_grid(0, grid, vd, scales[0], -1.0)
+    pc, nc = b.displace_grid_cascades(scales[:1], 0, grid, vd, -1.0)
+    assert np.array_equal(p1, pc) and np.array_equal(n1, nc)
+    side = grid + 1
+    y1 = p1[:, 1].reshape(side, side); y3 = pos[:, 1].reshape(side, side)
+    assert np.abs(y1[:, :256] - y1[:, 256:512]).max() <= 1e-3      # one tile: the period of the base tile
+    assert np.abs(y3[:, :256] - y3[:, 256:512]).max() > 1.0        # cascades: it is gone
+    with pytest.raises(W.OceanError):
+        b.displace_grid_cascades([1.0] * 4, 0, grid, vd)           # more cascades than tiles
+    b.close()

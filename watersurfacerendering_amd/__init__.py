@@ -187,6 +187,20 @@ class OceanBatch:
                    "ocean_read_grid")
         return pos, nrm
 
+    def displace_grid_cascades(self, uv_scales, first_tile: int = 0, grid_size: Optional[int] = None,
+                               vertex_distance: Optional[float] = None, choppy: float = -1.0):
+        """Sum of the tiles first_tile .. first_tile+len(uv_scales)-1 as cascades (ocean_displace_grid_cascades):
+        returns (positions, normals) like displace_grid."""
+        sc = np.ascontiguousarray(uv_scales, dtype=np.float32)
+        g = self.tile_size if grid_size is None else int(grid_size)
+        vd = (1000.0 / 512.0) if vertex_distance is None else float(vertex_distance)
+        _abi.check(self._L.ocean_displace_grid_cascades(self._h, first_tile, sc.size, g, vd, sc.ctypes.data_as(C.POINTER(C.c_float)), choppy),
+                   "ocean_displace_grid_cascades")
+        pos = np.empty(((g + 1) * (g + 1), 4), dtype=np.float32)
+        nrm = np.empty_like(pos)
+        _abi.check(self._L.ocean_read_grid(self._h, pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)), "ocean_read_grid")
+        return pos, nrm
+
     def bind_output(self, d_disp: int | None, d_nrm: int | None):
         _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")
 

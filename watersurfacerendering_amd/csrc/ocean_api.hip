@@ -665,6 +665,40 @@ int ocean_displace_grid(ocean_t* c, uint32_t tile, uint32_t grid_size, float ver
     return OCEAN_OK;
 }
 
+int ocean_displace_grid_cascades(ocean_t* c, uint32_t first_tile, uint32_t count, uint32_t grid_size, float vertex_distance,
+                                 const float* uv_scales, float choppy)
+{
+    if (!c || !uv_scales || count == 0 || count > (uint32_t)OCEAN_MAX_CASCADES || first_tile >= c->tiles || first_tile + count > c->tiles ||
+        grid_size == 0 || grid_size > 8192)
+        return OCEAN_E_INVALID;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t verts = (grid_size + 1) * (grid_size + 1);
+    if (verts > c->grid_capacity) {
+        SYNC_ALL(c);
+        if (c->grid_pos) (void)hipFree(c->grid_pos);
+        if (c->grid_nrm) (void)hipFree(c->grid_nrm);
+        c->grid_pos = c->grid_nrm = nullptr; c->grid_capacity = 0;
+        HIP_TRY(hipMalloc(&c->grid_pos, (size_t)verts * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->grid_nrm, (size_t)verts * sizeof(float4)));
+        c->grid_capacity = verts;
+    }
+    const size_t n2 = (size_t)c->n * c->n;
+    CascadeArgs a;
+    a.g.disp = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + first_tile * n2;
+    a.g.nrm = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + first_tile * n2;
+    a.g.minmax = c->minmax[c->last_set] + 2 * first_tile;
+    a.g.positions = c->grid_pos; a.g.normals = c->grid_nrm;
+    a.g.n = (int)c->n; a.g.grid = (int)grid_size;
+    a.g.vertex_distance = vertex_distance; a.g.uv_scale = 1.0f; a.g.choppy = choppy;
+    a.count = (int)count; a.tile_texels = n2;
+    for (uint32_t i = 0; i < (uint32_t)OCEAN_MAX_CASCADES; ++i) a.uv_scale[i] = i < count ? uv_scales[i] : 0.0f;
+    hipLaunchKernelGGL(k_displace_grid_cascades, dim3((verts + 255) / 256), dim3(256), 0, stream_of(c, c->last_set), a);
+    HIP_TRY(hipGetLastError());
+    c->grid_vertices = verts;
+    return OCEAN_OK;
+}
+
 int ocean_read_grid(ocean_t* c, float* positions, float* normals)
 {
     if (!c) return OCEAN_E_INVALID;

@@ -1086,6 +1086,49 @@ __global__ void k_displace_grid(const GridArgs g)
     g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
 }
 
+// Cascades (the reference's own to-do "Endless - solving the tiling artifacts", README.md:37-44): the
+// usual cure for the visible repetition of one FFT tile is to add several tiles of different lengths and seeds, each
+// sampled at its own rate.  The tiles of a batch already are independent oceans with their own tile length, so the
+// consumer only has to sum them: vertex = grid point + sum_c D_c(uv * s_c) (each height times its own amplitude A_c),
+// normal from the summed slopes and summed displacement derivatives with the reference's formula (.vert:34-38).
+// w carries the smallest Jacobian slot of the cascades (all 1 unless OCEAN_MODE_JACOBIAN).
+constexpr int OCEAN_MAX_CASCADES = 8;
+struct CascadeArgs {
+    GridArgs g;                        // disp / nrm / minmax of the FIRST tile of the cascade; n, grid, vertex_distance, choppy
+    int count;
+    size_t tile_texels;                // N * N
+    float uv_scale[OCEAN_MAX_CASCADES];
+};
+
+__global__ void k_displace_grid_cascades(const CascadeArgs a)
+{
+#pragma clang fp contract(off)
+    const GridArgs& g = a.g;
+    const int side = g.grid + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= side * side) return;
+    const int half = g.grid / 2;
+    const int xi = i % side - half, yi = i / side - half;
+    const float px = (float)xi * g.vertex_distance, pz = (float)yi * g.vertex_distance;
+    const float u = (float)(xi + half) / (float)g.grid, v = (float)(yi + half) / (float)g.grid;
+    float dx = 0.0f, dy = 0.0f, dz = 0.0f, w = 3.402823466e+38f;
+    float sx = 0.0f, sz = 0.0f, ddx = 0.0f, ddz = 0.0f;
+    for (int c = 0; c < a.count; ++c) {
+        const float us = u * a.uv_scale[c], vs = v * a.uv_scale[c];
+        const float amp = fmaxf(fabsf(key_float(g.minmax[2 * c + 0])), fabsf(key_float(g.minmax[2 * c + 1])));
+        const float4 d = sample_linear_repeat(g.disp + (size_t)c * a.tile_texels, g.n, us, vs);
+        const float4 sl = sample_linear_repeat(g.nrm + (size_t)c * a.tile_texels, g.n, us, vs);
+        dx = dx + d.x; dy = dy + d.y * amp; dz = dz + d.z;
+        w = fminf(w, d.w);
+        sx = sx + sl.x; sz = sz + sl.y; ddx = ddx + sl.z; ddz = ddz + sl.w;
+    }
+    g.positions[i] = make_float4(px + dx, 0.0f + dy, pz + dz, w);
+    const float nx = -(sx / (1.0f + g.choppy * ddx));
+    const float nz = -(sz / (1.0f + g.choppy * ddz));
+    const float len = sqrtf(nx * nx + 1.0f + nz * nz);
+    g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
+}
+
 #endif  // OCEAN_INIT_KERNELS
 
 // ---- per-size launch geometry ---------------------------------------------------
