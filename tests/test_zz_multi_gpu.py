@@ -1,5 +1,6 @@
 """Multi-GPU tests of the tile-sharded batch mode: they need at least two MI355X in the node and are
-skipped otherwise (a gpurun box has one).  One process per GPU, the library's own RCCL communicator
+skipped otherwise (a gpurun box has one).  The file sorts last on purpose: on a multi-GPU node these are the first runs of the
+gather over xGMI anywhere, and `pytest -x` must not let a surprise there hide the parity results.  One process per GPU, the library's own RCCL communicator
 (ocean_comm_init / ocean_gather_maps), every rank's tiles compared on the root bit for bit."""
 import json
 import os

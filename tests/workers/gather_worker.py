@@ -1,4 +1,4 @@
-"""Rank process of tests/test_multi_gpu.py: one GPU per rank, tiles sharded, the library's own RCCL gather.
+"""Rank process of tests/test_zz_multi_gpu.py: one GPU per rank, tiles sharded, the library's own RCCL gather.
 Launched by torch.distributed.run; prints GATHER_OK on rank 0 when every tile of every rank arrived intact."""
 import os
 import sys
