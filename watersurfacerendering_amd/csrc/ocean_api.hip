@@ -56,7 +56,7 @@ static void free_set(ocean_ctx* c, int i)
 static int alloc_set_buffers(ocean_ctx* c, int i)
 {
     const size_t n = c->n, n2 = n * n, t = c->tiles;
-    const size_t nu = n / 2 + 1, nup = n / 2 + 8;
+    const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
     // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
     HIP_TRY(hipMalloc(&c->z[i], t * 4 * nu * 2 * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
@@ -329,7 +329,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     if (c->inter_bits != c->inter_bits_zeroed) {
         // the two precisions lay the same elements out at 8 or 4 bytes each: what one wrote sits in the other's
         // padding columns, which must read as zero -> zero-fill every allocated chain again
-        const size_t nu = n / 2 + 1, nup = n / 2 + 8;
+        const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
         SYNC_ALL(c);
         for (int i = 0; i < MAXD; ++i)
             if (c->z[i]) {
@@ -452,13 +452,19 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.t = t;
     a.mode = c->mode;
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
-    int stream_maps = (c->n >= 4096 || pipe) ? 3 : 0;
+    const double texels = (double)c->tiles * (double)c->n * (double)c->n;
+    // several frames in flight, or maps that would push everything else out of the 256 MiB memory-side cache anyway
+    // (32 B/texel: 4096^2, 8 x 1024^2 ...): stream the maps past it.  A serial 2048^2 frame (134 MB of maps) is
+    // faster with plain stores (76 vs 80 us), a serial 8 x 1024^2 batch (268 MB) with streamed ones (124 vs 150 us).
+    int stream_maps = (pipe || texels * 32.0 > 200.0e6) ? 3 : 0;
     if (c->inter_bits == 16) stream_maps |= 8;          // bit 3: half2 intermediates (kernel variant, not a store policy)
-    {   // what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the
-        // 256 MiB memory-side cache: beyond it the intermediates are streamed too (bit 2, see store_z)
-        const double texels = (double)c->tiles * (double)c->n * (double)c->n;
-        const double resident = texels * (10.0 + (c->inter_bits == 16 ? 8.0 : 16.0) * (pipe ? c->depth : 1));
-        if (resident > 300.0e6) stream_maps |= 4;
+    if (pipe) {
+        // what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the memory-side
+        // cache: beyond it the intermediates are streamed too (bit 2, see store_z).  Never for a serial frame: its x pass
+        // reads them right behind the z pass, and 64-byte streamed pieces cost the z pass more than they save
+        // (4096^2 serial: 325 vs 350 us; profiles/r02_layout_experiments.txt).
+        const double resident = texels * (10.0 + (c->inter_bits == 16 ? 8.0 : 16.0) * c->depth);
+        if (resident > 330.0e6) stream_maps |= 4;
     }
     static const char* const split_env = getenv("OCEAN_ZSPLIT");                // developer override (A/B runs): 0 = never split
     if (!pipe && !(split_env && atoi(split_env) == 0)) stream_maps |= 16;       // this frame has the device to itself

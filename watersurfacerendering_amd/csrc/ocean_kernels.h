@@ -143,9 +143,10 @@ struct FrameArgs {
     const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
     const float2* tw;        // [N]             exp(+2 pi i k / N)
-    float2* z;               // [tiles][4][N/2+1][2][NUP] row-transformed pairs (the 4th only in OCEAN_MODE_JACOBIAN): row m, side 0 = columns
-                             //   u = 0..N/2, side 1 = columns (N-u)%N, NUP = N/2 + 8 (padded)
-    float2* zh;              // [tiles][N/2+1][NUP]      row-transformed height, columns 0..N/2
+    float2* z;               // [tiles][4][NUP/ZB][2][N/2+1][ZB] z-transformed pairs (the 4th only in OCEAN_MODE_JACOBIAN): element (column nb,
+                             //   side, row q) at Half<N>::zidx -- side 0 = rows q = 0..N/2, side 1 = rows (N-q)%N; NUP = N/2 + 16 rounded
+                             //   down to a multiple of 16; ZB = 8 rows per block (16 in the half2 form)
+    float2* zh;              // [tiles][NUP/ZB][N/2+1][ZB]   z-transformed height, rows 0..N/2 (Half<N>::zhidx)
     const float4* zscale;    // [tiles][2] powers of two of the half2 intermediates (Z16 kernels): [0] = (s_u, s_k, 1/s_u, 1/s_k) for the pairs
                              //   weighted by unit vectors / by k; [1] = (s_3, g, 1/s_3, 1/g) for pair 3 of the Jacobian mode, whose
                              //   cross-derivative part is first multiplied by g so that both parts have the height's magnitude
@@ -405,13 +406,38 @@ __device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
 }
 
 // ---- half-spectrum storage geometry -------------------------------------------
+#ifndef OCEAN_ZTILE
+#define OCEAN_ZTILE 8          // rows per block of the intermediates (fp32: 64-byte pieces)
+#endif
+#ifndef OCEAN_ZTILE_H
+#define OCEAN_ZTILE_H 16       // the same for half2 intermediates (64-byte pieces again)
+#endif
 template <int N> struct Half {
     static constexpr int NU = N / 2 + 1;          // columns (units) / rows kept: 0..N/2
-    static constexpr int NUP = N / 2 + 8;         // padded to a multiple of 8
+    static constexpr int NUP = (N / 2 + 16) & ~15;   // rows 0..N/2 padded to a multiple of 16
     static constexpr size_t Z_GROUP = (size_t)NU * 2 * NUP;       // float2 per packed pair
     static constexpr size_t Z_TILE = 4 * Z_GROUP;                 // pairs 0..2, and pair 3 = (height, cross derivative) of OCEAN_MODE_JACOBIAN
     static constexpr size_t ZH_TILE = (size_t)NU * NUP;
     static constexpr size_t HRAW_TILE = (size_t)NUP * N;          // floats
+    // element (column nb, side, row q) of a packed pair's group, and (column nb, row q) of the height's half plane:
+    // row-blocked, [q / ZB][side][nb][q % ZB], so that an x-pass workgroup -- which owns a few rows q and walks all columns
+    // nb -- reads one dense run per side instead of a small piece out of every column's 16.5 KB run, while the z pass still
+    // writes ZB units = 64 bytes at a time (OCEAN_ZTILE = 0: the column-major layout [nb][side][q] of round 1;
+    // profiles/r02_layout_experiments.txt has the A/B of 4-, 8- and 16-row blocks).
+    template <bool Z16> static constexpr int zb() { return OCEAN_ZTILE ? (Z16 ? OCEAN_ZTILE_H : OCEAN_ZTILE) : 8; }
+    static_assert(NUP % 16 == 0, "row blocks");
+    template <bool Z16> static __device__ __forceinline__ unsigned zidx(int nb, int side, int q)
+    {
+        constexpr int ZB = zb<Z16>();
+        if constexpr (OCEAN_ZTILE != 0) return (unsigned)(((q / ZB) * 2 + side) * (NU * ZB) + nb * ZB + (q % ZB));
+        else return (unsigned)((nb * 2 + side) * NUP + q);
+    }
+    template <bool Z16> static __device__ __forceinline__ unsigned zhidx(int nb, int q)
+    {
+        constexpr int ZB = zb<Z16>() > 8 ? zb<Z16>() : 8;       // the height role reads eight units per column
+        if constexpr (OCEAN_ZTILE != 0) return (unsigned)((q / ZB) * (NU * ZB) + nb * ZB + (q % ZB));
+        else return (unsigned)(nb * NUP + q);
+    }
 };
 // raw height of map row u at column p: rows of N floats, so that a wave working on one row reads
 // and writes 64 consecutive floats (an 8-row-interleaved layout cost the displacement pass 5 us)
@@ -455,8 +481,11 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     if (a.mode == 3) g3 = a.zscale[2 * tile + 1].y;
     // element offsets; the half2 form packs the same elements at 4 bytes each from the same base address
     constexpr size_t ES = Z16 ? 4 : 8;
-    float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + ((size_t)tile * HF::Z_TILE + (size_t)nb * 2 * HF::NUP) * ES);
-    float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + ((size_t)tile * HF::ZH_TILE + (size_t)nb * HF::NUP) * ES);
+    float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + (size_t)tile * HF::Z_TILE * ES);
+    float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
+    // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored positions 0 and N/2 exist on side 0
+    // only: the x pass knows)
+    auto zpos = [&](int p) -> unsigned { return p <= N / 2 ? HF::template zidx<Z16>(nb, 0, p) : HF::template zidx<Z16>(nb, 1, N - p); };
     // S+(e) and Tx(e), Tz(e)
     auto fetch = [&](int e, float& sv, float& tx, float& tz) {
         if constexpr (COL0) {
@@ -490,10 +519,10 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             return c == 2 ? make_float2(kx2 * g, kz * kz * g) : make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
-            const unsigned pos = (unsigned)(p <= N / 2 ? p : HF::NUP + (N - p));
+            const unsigned pos = zpos(p);
             if (c == 3) {
                 if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + pos, v, s3);
-                else if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);
+                else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb, p), v, su);
                 return;
             }
             if (a.mode == 2) return;
@@ -521,9 +550,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
-            // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored
-            // positions 0 and N/2 exist on side 0 only: the x pass knows)
-            store_z<ZNT, Z16>(zt, (unsigned)(c * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, c ? sk : su);
+            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zpos(p), v, c ? sk : su);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -558,11 +585,11 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16>(zt, (unsigned)(3 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, s3);
-                else if (p <= N / 2) store_z<ZNT, Z16>(zh, (unsigned)p, v, su);     // real input: other half is the conjugate
+                if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + zpos(p), v, s3);
+                else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb, p), v, su);     // real input: other half is the conjugate
                 return;
             }
-            store_z<ZNT, Z16>(zt, (unsigned)(2 * (int)HF::Z_GROUP + (p <= N / 2 ? p : HF::NUP + (N - p))), v, sk);
+            store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zpos(p), v, sk);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -605,6 +632,9 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     // that last round over two workgroups each, one per batch of transforms (both animate the column; a.zfull < N/2+1).
     int nb = (int)blockIdx.x, batches = 3;
     if (ZC == 2 && nb >= a.zfull) { const int r = nb - a.zfull; nb = a.zfull + (r >> 1); batches = 1 + (r & 1); }
+#if OCEAN_ZTILE
+    else nb = xcd_swizzle(nb, a.zfull);     // neighbouring columns write neighbouring 32-byte pieces: same XCD, same L2
+#endif
     const int nbb = (N - nb) & (N - 1);
     const size_t n2 = (size_t)N * N;
     const float2* __restrict__ h0 = a.h0 + tile * n2;
@@ -719,11 +749,11 @@ __device__ __forceinline__ c32 load_pair_column(const float2* __restrict__ zg, i
 #ifdef OCEAN_ABL_NOLOAD
     return make_float2(1.0f + mf, 0.5f * u);
 #endif
-    if (mf <= N / 2) return load_z<Z16>(zg, (unsigned)(mf * 2 * HF::NUP + u), unscale, unscale_y);
+    if (mf <= N / 2) return load_z<Z16>(zg, HF::template zidx<Z16>(mf, 0, u), unscale, unscale_y);
     // mirror of the self-mirrored units 0 and N/2 is the unit itself (side 0)
     const int side = (u == 0 || u == N / 2) ? 0 : 1;
-    if constexpr (Z16) return load_z<true>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), eps * unscale, eps * unscale_y);
-    const c32 v = load_z<false>(zg, (unsigned)(((N - mf) * 2 + side) * HF::NUP + u), 1.0f);
+    if constexpr (Z16) return load_z<true>(zg, HF::template zidx<Z16>(N - mf, side, u), eps * unscale, eps * unscale_y);
+    const c32 v = load_z<false>(zg, HF::template zidx<Z16>(N - mf, side, u), 1.0f);
     return make_float2(eps * v.x, eps * v.y);
 }
 
@@ -826,13 +856,13 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             const int row = nf <= N / 2 ? nf : N - nf;
             float4 z;
             if constexpr (Z16) {      // two half2 units in one 8-byte load
-                const float2 raw2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(zh) + (unsigned)(row * HF::NUP + u0 + 2 * c) * 4u);
+                const float2 raw2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(zh) + HF::template zhidx<Z16>(row, u0 + 2 * c) * 4u);
                 __half2 ha, hb;
                 __builtin_memcpy(&ha, &raw2.x, 4); __builtin_memcpy(&hb, &raw2.y, 4);
                 const float2 fa = __half22float2(ha), fb = __half22float2(hb);
                 z = make_float4(fa.x * uu, fa.y * uu, fb.x * uu, fb.y * uu);
             } else {
-                z = *reinterpret_cast<const float4*>(&at32(zh, (unsigned)(row * HF::NUP + u0 + 2 * c)));
+                z = *reinterpret_cast<const float4*>(&at32(zh, HF::template zhidx<Z16>(row, u0 + 2 * c)));
             }
             if (nf == 0 || nf == N / 2) return make_float2(z.x, z.z);
             if (nf < N / 2) return make_float2(z.x - z.w, z.y + z.z);
@@ -1149,6 +1179,8 @@ OCEAN_GEO(512, (zpass_columns<512>() == 4 ? 256 : 128), Plan<512>, 4, 256, Plan<
 // from 1024 up the z pass runs radix-8 butterflies with twice the threads (one more LDS
 // exchange, about half the VGPRs): -9 % at 1024, -1.5 % at 2048, -4.5 % at 4096
 OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), 4, 256, Plan<1024>)
+// (x pass with two rows per workgroup and 256 threads -- 106 VGPRs, four workgroups per CU instead of one -- is 15 % slower at 2048
+// and 1024: 16- instead of 32-byte pieces of the intermediates; profiles/r02_layout_experiments.txt)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), 4, 512, Plan<2048>)
 OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), 2, 512, Plan<4096>)
 #undef OCEAN_GEO
