@@ -517,11 +517,11 @@ def main():
     # serial frames -- a per-launch duration only characterises a kernel that has the GPU to itself; the
     # pipelined durations are reported beside them
     kern_ms_pipe = None
-    nk = max(3, min(args.steps, 200))
+    nk = 200                    # launches averaged per kernel, whatever --steps is (a 20-step run would average 20 noisy ones)
     if args.depth > 1:
-        _, kern_ms_pipe = b.time_frames(0.0, DT, 50, nk, per_kernel=True)
+        _, kern_ms_pipe = b.time_frames(0.0, DT, 200, nk, per_kernel=True)
         b.set_pipeline_depth(1)
-    ms_serial, kern_ms = b.time_frames(0.0, DT, 50, nk, per_kernel=True)
+    ms_serial, kern_ms = b.time_frames(0.0, DT, 200, nk, per_kernel=True)
     serial_us_per_step = ms_serial / nk * 1e3
     b.set_pipeline_depth(args.depth)
     names = b.kernel_names()

@@ -76,12 +76,14 @@ def traffic(path, n, tiles=1, fetch_factor=2.0):
             ent["correction"] = (f"FETCH_SIZE x {fetch_factor}: its loads are coalesced (16 / 4 bytes per lane), for which "
                                  "tools/ubench/fetchcal.hip measures known bytes / FETCH_SIZE = 2.000 (128-byte requests tallied at 64: "
                                  "MI355X_MICROARCH.md HBM section; profiles/r02_fetch_calibration.txt); WRITE_SIZE as read")
-        else:       # the x passes gather 32-byte pieces: the request size of such reads is not observable
+        else:       # the x passes read 32-byte halves of 64-byte pieces out of dense runs (row-blocked intermediates)
             ent["hbm_bytes_per_launch_low"] = int(v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024)
-            ent["correction"] = (f"UPPER bound: FETCH_SIZE x {fetch_factor} as for coalesced reads.  These kernels read 32-byte pieces of "
-                                 "16.5 KB-strided rows; for that shape fetchcal measures FETCH_SIZE ALREADY 1.4-1.9 x the useful bytes (64-byte "
-                                 "requests for 32-byte pieces) and the counters cannot tell 64- from 128-byte requests, so the true figure "
-                                 "lies between hbm_bytes_per_launch_low (x 1) and this one (profiles/r02_fetch_calibration.txt); WRITE_SIZE as read")
+            ent["correction"] = (f"FETCH_SIZE x {fetch_factor} as for coalesced reads.  With the row-blocked intermediates these kernels read dense "
+                                 "runs (a workgroup uses 32 bytes of every 64-byte piece, its neighbour on the same XCD the other 32), and the "
+                                 "x 2 reading lands within 10 % of the algorithmic bytes; with the column-major layout of the first half of the "
+                                 "round (32-byte pieces at a 16.5 KB stride) the raw counter alone was already 1.4-1.9 x the useful bytes "
+                                 "(profiles/r02_fetch_calibration.txt).  hbm_bytes_per_launch_low = the x 1 reading, kept as the lower bound; "
+                                 "WRITE_SIZE as read")
         out[key] = ent
     save("traffic.json", out)
 

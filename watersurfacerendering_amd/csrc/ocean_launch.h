@@ -107,7 +107,11 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
     {
         const bool jac = a.mode == 3;       // OCEAN_MODE_JACOBIAN: the height role works on pair 3, C rows per workgroup
-        const dim3 gb((jac ? nb : hb_b) + nb, tiles), gd(nb, tiles), blk(G::T_C);
+        dim3 gb((jac ? nb : hb_b) + nb, tiles), gd(nb, tiles), blk(G::T_C);
+#ifdef OCEAN_XBGRID
+        if (const char* ev = getenv("OCEAN_DEBUG_XB_GRID")) gb.x = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
+        if (const char* ev = getenv("OCEAN_DEBUG_XD_GRID")) gd.x = (unsigned)atoi(ev);
+#endif
         hipEvent_t* mb = marks ? marks + 2 : nullptr;
         hipEvent_t* md = marks ? marks + 4 : nullptr;
 #define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16)                                                                \
