@@ -239,6 +239,20 @@ int ocean_displace_grid_cascades(ocean_t* ctx, uint32_t first_tile, uint32_t cou
 int ocean_read_grid(ocean_t* ctx, float* positions, float* normals);
 int ocean_device_grid(ocean_t* ctx, void** d_positions, void** d_normals, uint32_t* vertices);
 
+/* Mip chain of one tile's maps: the reference's LOD hook.  Its map textures are created and filled with a
+ * `mipmapping` flag (s_kUseMipMapping, WaterSurfaceMesh.h:216, passed at WaterSurfaceMesh.cpp:611-618,652-690; off in the
+ * shipped build, "LOD. anti-aliasing" on its to-do list, README.md:37-44); when set, Texture2D::GenerateMipmaps
+ * (vulkan/Texture2D.cpp:228-330) blits level i-1 into level i at half the extent with VK_FILTER_LINEAR,
+ * floor(log2(N)) + 1 levels in all.  ocean_build_mips does the same for both maps of `tile` behind the frame that wrote
+ * them: levels 1 .. log2(N) (level 0 is the map itself), each texel the 2 x 2 mean of the level above, tightly packed
+ * one after another -- level l starts at texel sum_{k=1}^{l-1} (N >> k)^2, ocean_mip_texels(N) = (N^2 - 1) / 3 texels
+ * of RGBA32F per map.  Results stay in device buffers owned by the context: ocean_read_mips copies them out
+ * (synchronises), ocean_device_mips hands out the pointers and the number of levels.                                  */
+size_t ocean_mip_texels(uint32_t tile_size);
+int ocean_build_mips(ocean_t* ctx, uint32_t tile);
+int ocean_read_mips(ocean_t* ctx, float* disp_mips, float* nrm_mips);
+int ocean_device_mips(ocean_t* ctx, void** d_disp_mips, void** d_nrm_mips, uint32_t* levels);
+
 /* The hipStream_t the most recent frame was enqueued on (as void*), and a way
  * to make the context use ONE caller-owned stream instead (this also disables
  * pipelining; NULL = back to the context's own streams).                         */

@@ -84,3 +84,18 @@ def displace_grid_cascades(disps, nrms, amps, uv_scales, grid: int, vertex_dista
     nz = -(s[:, 1] / (F(1.0) + F(choppy) * s[:, 3]))
     ln = np.sqrt(nx * nx + F(1.0) + nz * nz)
     return pos, np.stack([nx / ln, F(1.0) / ln, nz / ln, np.zeros_like(nx)], axis=1).astype(np.float32)
+
+
+def mip_chain(tex: np.ndarray):
+    """The reference's mip chain of a map (s_kUseMipMapping, WaterSurfaceMesh.h:216; Texture2D::GenerateMipmaps,
+    vulkan/Texture2D.cpp:228-330: level i = vkCmdBlitImage(VK_FILTER_LINEAR) of level i-1 into half the extent, floor(log2 N) + 1
+    levels).  An exact 2:1 linear blit samples the corner shared by four source texels: the bilinear formula above with both
+    weights 1/2, in the same evaluation order.  Returns levels 1 .. log2 N, [(N >> l, N >> l, 4)].  PARITY UNPINNED (Vulkan
+    leaves the blit filter's precision to the implementation; the shipped reference has the switch off)."""
+    lv, cur = [], np.ascontiguousarray(tex, dtype=np.float32)
+    h = F(0.5)
+    while cur.shape[0] > 1:
+        t00, t10, t01, t11 = cur[0::2, 0::2], cur[0::2, 1::2], cur[1::2, 0::2], cur[1::2, 1::2]
+        cur = ((t00 * h + t10 * h) * h + (t01 * h + t11 * h) * h).astype(np.float32)
+        lv.append(cur)
+    return lv

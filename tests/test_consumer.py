@@ -138,3 +138,50 @@ def test_cascade_consumer_matches_oracle_on_tiles_of_different_length():
     with pytest.raises(W.OceanError):
         b.displace_grid_cascades([1.0] * 4, 0, grid, vd)           # more cascades than tiles
     b.close()
+
+
+def test_oracle_mip_chain_is_the_2x2_mean_down_to_one_texel():
+    """Texture2D.cpp:228-330 (level i = linear blit of level i-1 into half the extent; floor(log2 N) + 1 levels): levels 1 .. log2 N,
+    each the mean of 2 x 2 texels of the one above, the last one the mean of the whole map."""
+    from oracle import consumer as C
+    n = 32
+    disp, _ = _maps(n, 3)
+    lv = C.mip_chain(disp)
+    assert [l.shape for l in lv] == [(n >> k, n >> k, 4) for k in range(1, 6)]
+    want = 0.25 * (disp[0::2, 0::2] + disp[0::2, 1::2] + disp[1::2, 0::2] + disp[1::2, 1::2])
+    assert np.allclose(lv[0], want, rtol=0, atol=1e-6)
+    assert np.allclose(lv[-1][0, 0], disp.reshape(-1, 4).mean(0), rtol=0, atol=1e-5)
+    assert np.array_equal(lv[0][..., 3], np.ones((n // 2, n // 2), np.float32))      # displacement.w = 1 survives every level
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,tiles,tile", [(16, 1, 0), (256, 3, 2), (1024, 1, 0)])
+def test_mip_chain_matches_oracle(n, tiles, tile):
+    """ocean_build_mips / ocean_read_mips / ocean_device_mips against oracle/consumer.py::mip_chain of the maps the same frame
+    read out: bit for bit (products by 1/2 are exact, the sums are taken in the same order)."""
+    import ctypes
+    import watersurfacerendering_amd as W
+    from oracle import consumer as C
+    b = W.OceanBatch(n, tiles, 0)
+    b.prepare(0x5EED0000 + n)
+    with pytest.raises(W.OceanError):
+        b.build_mips(0)                                          # no frame yet
+    b.compute_waves(1.25)
+    disp, nrm = b.read_maps()
+    dl, ql = b.build_mips(tile)
+    od, oq = C.mip_chain(disp[tile]), C.mip_chain(nrm[tile])
+    assert len(dl) == len(od) == n.bit_length() - 1
+    for got, want in zip(dl + ql, od + oq):
+        assert got.shape == want.shape and np.array_equal(got, want)
+    assert int(b._L.ocean_mip_texels(n)) == (n * n - 1) // 3 == sum(l.shape[0] * l.shape[1] for l in od)
+    pd, pq, lv = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+    assert b._L.ocean_device_mips(b._h, ctypes.byref(pd), ctypes.byref(pq), ctypes.byref(lv)) == 0
+    assert pd.value and pq.value and lv.value == len(od)
+    with pytest.raises(W.OceanError):
+        b.build_mips(tiles)                                      # no such tile
+    # a second frame, asynchronously: the chain is built behind it on the same stream
+    b.compute_waves_async(2.5)
+    dl2, _ = b.build_mips(tile)
+    disp2, _ = b.read_maps()
+    assert np.array_equal(dl2[0], C.mip_chain(disp2[tile])[0])
+    b.close()

@@ -201,6 +201,20 @@ class OceanBatch:
         _abi.check(self._L.ocean_read_grid(self._h, pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)), "ocean_read_grid")
         return pos, nrm
 
+    def build_mips(self, tile: int = 0):
+        """Mip chain of both maps of `tile` (ocean_build_mips: the reference's s_kUseMipMapping path, Texture2D.cpp:228-330):
+        returns (disp_levels, nrm_levels), lists of (N >> l, N >> l, 4) float32 arrays for l = 1 .. log2 N."""
+        _abi.check(self._L.ocean_build_mips(self._h, tile), "ocean_build_mips")
+        texels = int(self._L.ocean_mip_texels(self.tile_size))
+        d = np.empty((texels, 4), dtype=np.float32)
+        q = np.empty_like(d)
+        _abi.check(self._L.ocean_read_mips(self._h, d.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)), "ocean_read_mips")
+        out_d, out_q, off, w = [], [], 0, self.tile_size // 2
+        while w >= 1:
+            out_d.append(d[off:off + w * w].reshape(w, w, 4)); out_q.append(q[off:off + w * w].reshape(w, w, 4))
+            off += w * w; w //= 2
+        return out_d, out_q
+
     def bind_output(self, d_disp: int | None, d_nrm: int | None):
         _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")
 

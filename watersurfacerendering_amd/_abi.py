@@ -37,6 +37,7 @@ SYMBOLS = [
     "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_bind_output",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
+    "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
     "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
     "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
 ]
@@ -126,6 +127,10 @@ def lib() -> C.CDLL:
         "ocean_displace_grid_cascades": (i32, [P, u32, u32, u32, f32, FP, f32]),
         "ocean_read_grid": (i32, [P, C.c_void_p, C.c_void_p]),
         "ocean_device_grid": (i32, [P, C.POINTER(P), C.POINTER(P), C.POINTER(u32)]),
+        "ocean_mip_texels": (C.c_size_t, [u32]),
+        "ocean_build_mips": (i32, [P, u32]),
+        "ocean_read_mips": (i32, [P, C.c_void_p, C.c_void_p]),
+        "ocean_device_mips": (i32, [P, C.POINTER(P), C.POINTER(P), C.POINTER(u32)]),
         "ocean_set_mode": (i32, [P, i32]),
         "ocean_set_dispersion": (i32, [P, i32, f32]),
         "ocean_set_spectrum_precision": (i32, [P, i32]),

@@ -209,6 +209,8 @@ void ocean_destroy(ocean_t* c)
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->grid_pos) (void)hipFree(c->grid_pos);
+    if (c->mips_disp) (void)hipFree(c->mips_disp);
+    if (c->mips_nrm) (void)hipFree(c->mips_nrm);
     if (c->grid_nrm) (void)hipFree(c->grid_nrm);
     if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
@@ -722,6 +724,61 @@ int ocean_device_grid(ocean_t* c, void** d_positions, void** d_normals, uint32_t
     if (d_positions) *d_positions = c->grid_pos;
     if (d_normals) *d_normals = c->grid_nrm;
     if (vertices) *vertices = c->grid_vertices;
+    return OCEAN_OK;
+}
+
+size_t ocean_mip_texels(uint32_t n) { return ((size_t)n * n - 1) / 3; }      // sum of (n >> l)^2, l = 1 .. log2 n
+
+int ocean_build_mips(ocean_t* c, uint32_t tile)
+{
+    if (!c || tile >= c->tiles) return OCEAN_E_INVALID;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = c->n;
+    if (c->mips_n != n) {
+        SYNC_ALL(c);
+        if (c->mips_disp) (void)hipFree(c->mips_disp);
+        if (c->mips_nrm) (void)hipFree(c->mips_nrm);
+        c->mips_disp = c->mips_nrm = nullptr; c->mips_n = 0; c->mips_ready = false;
+        HIP_TRY(hipMalloc(&c->mips_disp, ocean_mip_texels(n) * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->mips_nrm, ocean_mip_texels(n) * sizeof(float4)));
+        c->mips_n = n;
+    }
+    const size_t n2 = (size_t)n * n;
+    MipArgs m;
+    m.src[0] = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + tile * n2;
+    m.src[1] = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + tile * n2;
+    m.dst[0] = c->mips_disp; m.dst[1] = c->mips_nrm;
+    hipStream_t st = stream_of(c, c->last_set);            // ordered after the frame that wrote these maps
+    for (uint32_t w = n / 2; w >= 1; w /= 2) {
+        m.w = (int)w;
+        hipLaunchKernelGGL(k_mip_level, dim3((w * w + 255) / 256, 2), dim3(256), 0, st, m);
+        m.src[0] = m.dst[0]; m.src[1] = m.dst[1];
+        m.dst[0] += (size_t)w * w; m.dst[1] += (size_t)w * w;
+    }
+    HIP_TRY(hipGetLastError());
+    c->mips_ready = true;
+    return OCEAN_OK;
+}
+
+int ocean_read_mips(ocean_t* c, float* disp_mips, float* nrm_mips)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (!c->mips_ready) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    const size_t bytes = ocean_mip_texels(c->mips_n) * sizeof(float4);
+    if (disp_mips) HIP_TRY(hipMemcpy(disp_mips, c->mips_disp, bytes, hipMemcpyDeviceToHost));
+    if (nrm_mips) HIP_TRY(hipMemcpy(nrm_mips, c->mips_nrm, bytes, hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int ocean_device_mips(ocean_t* c, void** d_disp_mips, void** d_nrm_mips, uint32_t* levels)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (d_disp_mips) *d_disp_mips = c->mips_ready ? c->mips_disp : nullptr;
+    if (d_nrm_mips) *d_nrm_mips = c->mips_ready ? c->mips_nrm : nullptr;
+    if (levels) { uint32_t l = 0; for (uint32_t w = c->mips_n; c->mips_ready && w > 1; w /= 2) ++l; *levels = l; }
     return OCEAN_OK;
 }
 

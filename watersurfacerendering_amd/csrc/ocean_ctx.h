@@ -75,6 +75,10 @@ struct ocean_ctx {
     float4* grid_pos = nullptr;     // vertex-stage consumer output (ocean_displace_grid)
     float4* grid_nrm = nullptr;
     uint32_t grid_vertices = 0, grid_capacity = 0;
+    float4* mips_disp = nullptr;    // mip chain of one tile's maps (ocean_build_mips): levels 1 .. log2 N, tightly packed
+    float4* mips_nrm = nullptr;
+    uint32_t mips_n = 0;            // tile size the two buffers were allocated for
+    bool mips_ready = false;
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
     hipEvent_t end_ev[MAXD] = {};       //                    end of every chain

@@ -1159,6 +1159,30 @@ __global__ void k_displace_grid_cascades(const CascadeArgs a)
     g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
 }
 
+// Mip chain of the maps (the reference's LOD hook: s_kUseMipMapping, WaterSurfaceMesh.h:216; Texture2D::GenerateMipmaps,
+// vulkan/Texture2D.cpp:228-330 -- level i = vkCmdBlitImage(VK_FILTER_LINEAR) of level i-1 into half the extent).  An exact 2:1
+// linear blit samples the point shared by four source texels: the bilinear formula of sample_linear_repeat with both weights
+// 1/2, evaluated in the same order (oracle/consumer.py::mip_chain repeats it).  One launch per level, both maps per launch
+// (blockIdx.y); a level is N^2/4^l texels, so everything after the first two is launch latency.
+struct MipArgs {
+    const float4* src[2];    // level l-1 of the displacement map, of the normal map
+    float4* dst[2];          // level l
+    int w;                   // extent of level l (source extent 2w)
+};
+__global__ void k_mip_level(const MipArgs m)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m.w * m.w) return;
+    const int x = i % m.w, y = i / m.w, sw = 2 * m.w;
+    const float4* __restrict__ s = m.src[blockIdx.y];
+    const float4 t00 = s[(unsigned)((2 * y) * sw + 2 * x)], t10 = s[(unsigned)((2 * y) * sw + 2 * x + 1)];
+    const float4 t01 = s[(unsigned)((2 * y + 1) * sw + 2 * x)], t11 = s[(unsigned)((2 * y + 1) * sw + 2 * x + 1)];
+    auto mix = [](float c00, float c10, float c01, float c11) { return (c00 * 0.5f + c10 * 0.5f) * 0.5f + (c01 * 0.5f + c11 * 0.5f) * 0.5f; };
+    m.dst[blockIdx.y][i] = make_float4(mix(t00.x, t10.x, t01.x, t11.x), mix(t00.y, t10.y, t01.y, t11.y),
+                                       mix(t00.z, t10.z, t01.z, t11.z), mix(t00.w, t10.w, t01.w, t11.w));
+}
+
 #endif  // OCEAN_INIT_KERNELS
 
 // ---- per-size launch geometry ---------------------------------------------------
