@@ -464,6 +464,30 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
 #define OCEAN_ZC4 1
 #endif
 template <int N> constexpr int zpass_columns() { return (OCEAN_ZC4 && N == 512) ? 4 : 2; }
+// Spectrum columns per z-pass workgroup.  Two NEIGHBOURING columns (each batch = the same pair of both columns) make every
+// store instruction of the last stage cover whole 128-byte lines of the row-blocked intermediates (2 x 64-byte pieces side by
+// side) instead of half lines -- what the non-temporal stores of big tiles and batches need.  Costs N more floats of LDS (a
+// second S+ table) and doubles the workgroup's chain, so only where the workgroups per CU do not change.
+// The launcher picks (k_zpass<..., ZW>): always at 4096^2 (one workgroup per CU either way: z pass 150 -> 132 us), from 1024 up
+// whenever the intermediates are streamed; never for a single small tile, whose few, longer workgroups would leave the chip
+// emptier (1024^2 z pass 16.0 -> 18.4 us).
+template <int N> constexpr bool zpass_has_width2() { return zpass_columns<N>() == 2 && N >= 1024; }
+
+// The first-stage input of one z-axis transform at element e of a spectrum column: pair 0 (uz Tz, -ux Tx), pair 1
+// (-kz Tz, kx Tx), pair 2 (kx ux S+, kz uz S+), pair 3 (S+, g3 kx uz Tc).  ONE definition with contraction off, so that every
+// z-pass variant (two or four transforms per batch, one or two columns per workgroup) feeds bit-identical values to its
+// transforms: frames are bit-identical whatever variant the launcher picks (tests/test_parity_bench_regimes.py).
+template <int PAIR>
+__device__ __forceinline__ c32 zpass_input(float kx, float kx2, float kz, float sv, float tx, float tz, float tc, float gate, bool jac, float g3)
+{
+#pragma clang fp contract(off)
+    const float d = __builtin_fmaf(kz, kz, kx2);
+    const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;              // |k| > 1e-5 (.h:135)
+    if constexpr (PAIR == 0) { const float f = inv * gate; return make_float2(kz * f * tz, -kx * f * tx); }
+    else if constexpr (PAIR == 1) { const float f = -1.0f * gate; return make_float2(kz * f * tz, -kx * f * tx); }
+    else if constexpr (PAIR == 2) { const float g = gate * inv * sv; return make_float2(kx2 * g, (kz * kz) * g); }
+    else return make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
+}
 
 template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
@@ -508,7 +532,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             float sv, tx, tz;
             fetch(e, sv, tx, tz);
             const float kz = kzt[e];
-            const float d = kx2 + kz * kz;
+            const float d = __builtin_fmaf(kz, kz, kx2);
             const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;      // |k| > 1e-5 (.h:135)
             if (c < 2) {
                 const float f = (c ? -1.0f : inv) * choppy;        // pair 1: (-kz Tz, kx Tx); pair 0: (uz Tz, -ux Tx)
@@ -535,13 +559,15 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     // -- batch A: slot 0 = pair 0 (Dx, Dz), slot 1 = pair 1 (sx, sz) ------------
     if (a.mode != 2 && (batches & 1)) {
         auto in = [&](int e, int c, int, int) -> c32 {
+#pragma clang fp contract(off)
             float sv, tx, tz;
             fetch(e, sv, tx, tz);
 #ifdef OCEAN_ABL_NOIN
             return make_float2(sv, tx);
 #endif
+            // (same operations, same order as zpass_input<0/1>, no contraction: bit-identical to the two-column variant)
             const float kz = kzt[e];
-            const float d = kx2 + kz * kz;
+            const float d = __builtin_fmaf(kz, kz, kx2);
             const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;      // |k| > 1e-5 (.h:135)
             const float f = c ? -1.0f : inv;                       // pair 1: (-kz Tz, kx Tx); pair 0: (uz Tz, -ux Tx)
             return make_float2(kz * f * tz, -kx * f * tx);
@@ -564,20 +590,22 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     const bool jac = a.mode == 3;
     if (batches & 2) {
         auto in = [&](int e, int c, int, int) -> c32 {
+#pragma clang fp contract(off)
             float sv, tx, tz;
             fetch(e, sv, tx, tz);
 #ifdef OCEAN_ABL_NOIN
             return make_float2(sv, tx);
 #endif
             const float kz = kzt[e];
-            const float kz2 = kz * kz;
-            const float d = kx2 + kz2;
-            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;
-            const float g = full7 * inv * sv;                      // pair 2 only exists in the 7-field modes
             // cross derivative: kx kz / |k| is odd in kx and in kz separately, so on the self-mirrored Nyquist column
             // (nb == 0) or row (e == 0) -- where one component of k(-idx) keeps its sign -- its Hermitian part takes
             // S- instead of S+ (both at once: S+ again)
             const float tc = COL0 ? (e == 0 ? sv : tx) : tz;
+            // (same operations, same order as zpass_input<2/3>, no contraction)
+            const float kz2 = kz * kz;
+            const float d = __builtin_fmaf(kz, kz, kx2);
+            const float inv = d > 1e-10f ? rsqrtf(d) : 0.0f;
+            const float g = full7 * inv * sv;                      // pair 2 only exists in the 7-field modes
             return make_float2(c ? sv : kx2 * g, c ? (jac ? g3 * (kx * kz * inv * tc) : 0.0f) : kz2 * g);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
@@ -594,6 +622,139 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
     }
+    }
+}
+
+// Two neighbouring spectrum columns nb0, nb0 + 1 (neither the Nyquist column 0 nor beyond N/2) in one workgroup: four batches
+// of two interleaved transforms, batch g = pair g (g = 3: the height, or pair 3 of the Jacobian mode) of BOTH columns, so that
+// lanes 0-31 / 32-63 of a last-stage store hold the same 32 rows of column nb0 / nb0 + 1: 4 x (64 + 64) contiguous bytes.
+template <int N, int T, class P, bool H16, bool W16, bool ZNT, bool Z16>
+__device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned char* smem, const TwiddleRegs<N, 2, T, P>& twr,
+                                                  int tid, int tile, int nb0)
+{
+    using HF = Half<N>;
+    c32* fbuf = reinterpret_cast<c32*>(smem);
+    float* sp0 = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());   // S+ of column nb0, of column nb0 + 1
+    float* sp1 = sp0 + N;
+    float* kzt = sp1 + N;
+    float* raw = reinterpret_cast<float*>(fbuf);                           // h~ of columns nb0, nb0+1, N-nb0, N-nb0-1 (16 N of the 17 N bytes)
+    const size_t n2 = (size_t)N * N;
+    const float2* __restrict__ h0 = a.h0 + tile * n2;
+    const float* __restrict__ om = a.omega + tile * n2;
+    const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
+    const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
+    [[maybe_unused]] const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
+    [[maybe_unused]] const float base = W16 ? a.base_freq[tile] : 0.0f;
+    [[maybe_unused]] const uint16_t* __restrict__ oq = a.omega_q + tile * n2;
+    {
+        constexpr int ELEMS = 2 * N;                  // 4 columns * N/2 element pairs
+        constexpr int P1 = ELEMS / T;
+        constexpr int PB = P1 > 4 ? 4 : P1;
+        static_assert(ELEMS % T == 0 && P1 % PB == 0, "phase-1 batches");
+#pragma unroll 1
+        for (int ub = 0; ub < P1; ub += PB) {
+            float4 hv[PB];
+            float2 wv[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = tid + (ub + u) * T;
+                const int s = e / (N / 2);
+                const int n = (e % (N / 2)) * 2;
+                const int col = (s & 2) ? ((N - nb0 - (s & 1)) & (N - 1)) : nb0 + (s & 1);
+                const size_t g = (size_t)col * N + n;
+                if constexpr (H16) {
+                    const float2 raw2 = *reinterpret_cast<const float2*>(a.h0h + tile * n2 + g);
+                    const __half2 ha = *reinterpret_cast<const __half2*>(&raw2.x);
+                    const __half2 hb = *reinterpret_cast<const __half2*>(&raw2.y);
+                    const float2 fa = __half22float2(ha), fb = __half22float2(hb);
+                    hv[u] = make_float4(fa.x * h16s, fa.y * h16s, fb.x * h16s, fb.y * h16s);
+                } else {
+                    hv[u] = *reinterpret_cast<const float4*>(h0 + g);
+                }
+                if constexpr (W16) {
+                    const unsigned two = *reinterpret_cast<const unsigned*>(oq + g);
+                    wv[u] = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+                } else {
+                    wv[u] = *reinterpret_cast<const float2*>(om + g);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = tid + (ub + u) * T;
+                const int s = e / (N / 2);
+                const int n = (e % (N / 2)) * 2;
+                float2 v;
+                v.x = animate(hv[u].x, hv[u].y, wv[u].x, t);
+                v.y = animate(hv[u].z, hv[u].w, wv[u].y, t);
+                *reinterpret_cast<float2*>(raw + s * N + n) = v;
+            }
+        }
+    }
+    __syncthreads();
+    const float sm00 = 0.5f * (raw[0] - raw[2 * N]), sm01 = 0.5f * (raw[N] - raw[3 * N]);      // S-(0) of the two columns
+    for (int e = tid; e < N; e += T) {
+        const int me = (N - e) & (N - 1);
+        sp0[e] = 0.5f * (raw[e] + raw[2 * N + me]);
+        sp1[e] = 0.5f * (raw[N + e] + raw[3 * N + me]);
+        kzt[e] = k1[e];
+    }
+    __syncthreads();
+
+    [[maybe_unused]] float su = 1.0f, sk = 1.0f, s3 = 1.0f;
+    float g3 = 1.0f;
+    if constexpr (Z16) { const float4 zs = a.zscale[2 * tile]; su = zs.x; sk = zs.y; s3 = a.zscale[2 * tile + 1].x; }
+    if (a.mode == 3) g3 = a.zscale[2 * tile + 1].y;
+    constexpr size_t ES = Z16 ? 4 : 8;
+    float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + (size_t)tile * HF::Z_TILE * ES);
+    float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
+    const float kx0 = k1[nb0], kx1 = k1[nb0 + 1];
+    const bool jac = a.mode == 3;
+    auto zpos = [&](int p, int c) -> unsigned { return p <= N / 2 ? HF::template zidx<Z16>(nb0 + c, 0, p) : HF::template zidx<Z16>(nb0 + c, 1, N - p); };
+    // S+(e), Tz(e) (Tx = S+ off the Nyquist column), kx of column c
+    const float kx20 = kx0 * kx0, kx21 = kx1 * kx1;
+    auto fetch = [&](int e, int c, float& sv, float& tz, float& kx, float& kx2) {
+        sv = c ? sp1[e] : sp0[e];
+        tz = (e == 0) ? (c ? sm01 : sm00) : sv;
+        kx = c ? kx1 : kx0;
+        kx2 = c ? kx21 : kx20;
+    };
+    if (a.mode != 2) {
+        {   // pair 0: (uz Tz, -ux Tx)
+            auto in = [&](int e, int c, int, int) -> c32 {
+                float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
+                return zpass_input<0>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
+            };
+            auto out = [&](int p, int c, c32 v, int, int) { store_z<ZNT, Z16>(zt, zpos(p, c), v, su); };
+            batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
+        }
+        {   // pair 1: (-kz Tz, kx Tx)
+            auto in = [&](int e, int c, int, int) -> c32 {
+                float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
+                return zpass_input<1>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
+            };
+            auto out = [&](int p, int c, c32 v, int, int) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zpos(p, c), v, sk); };
+            batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
+        }
+    }
+    if (a.mode == 0 || a.mode == 3) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
+        auto in = [&](int e, int c, int, int) -> c32 {
+            float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
+            return zpass_input<2>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
+        };
+        auto out = [&](int p, int c, c32 v, int, int) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zpos(p, c), v, sk); };
+        batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
+    }
+    {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
+        auto in = [&](int e, int c, int, int) -> c32 {
+            float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
+            if (!jac) return make_float2(sv, 0.0f);
+            return zpass_input<3>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, true, g3);
+        };
+        auto out = [&](int p, int c, c32 v, int, int) {
+            if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + zpos(p, c), v, s3);
+            else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb0 + c, p), v, su);     // real input: other half is the conjugate
+        };
+        batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
 }
 
@@ -615,7 +776,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
 // 1024 and 4096 would spill at that cap and keep the looser one
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
-template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false, bool Z16 = false>
+template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false, bool Z16 = false, int ZW = 1>
 __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -630,11 +791,10 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     // Serial frames of a tile whose columns do not fill the chip in whole rounds (2048^2: 1025 columns on 768 resident
     // workgroups) end with a round of lone workgroups, each a long dependent chain: the host then splits the columns of
     // that last round over two workgroups each, one per batch of transforms (both animate the column; a.zfull < N/2+1).
-    int nb = (int)blockIdx.x, batches = 3;
-    if (ZC == 2 && nb >= a.zfull) { const int r = nb - a.zfull; nb = a.zfull + (r >> 1); batches = 1 + (r & 1); }
-#if OCEAN_ZTILE
-    else nb = xcd_swizzle(nb, a.zfull);     // neighbouring columns write neighbouring 32-byte pieces: same XCD, same L2
-#endif
+    static_assert(ZW == 1 || zpass_has_width2<N>(), "two columns per workgroup: two-batch sizes from 1024 up");
+    TwiddleRegs<N, ZC, T, P> twr;
+    twr.load(a.tw, tid);
+    auto one_column = [&](const int nb, const int batches) {
     const int nbb = (N - nb) & (N - 1);
     const size_t n2 = (size_t)N * N;
     const float2* __restrict__ h0 = a.h0 + tile * n2;
@@ -647,8 +807,6 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     [[maybe_unused]] const uint16_t* __restrict__ oq = a.omega_q + tile * n2;
 
     OCEAN_STAMP(0);
-    TwiddleRegs<N, ZC, T, P> twr;
-    twr.load(a.tw, tid);
     // -- phase 1: animate columns nb and nbb; all loads issued before the first sincos
     {
         constexpr int ELEMS = N;                      // 2 columns * N/2 element pairs
@@ -722,6 +880,29 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
 
     if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
     else zpass_transforms<N, T, P, false, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
+    };
+
+    if constexpr (ZW == 2) {
+        // N/4 + 1 workgroups: block 0 = the Nyquist column 0 and column 1 one after the other, blocks 1 .. N/4-1 = columns
+        // 2b, 2b+1 together, the last one = column N/2 alone (dispatched last: the shortest job closes the grid)
+        constexpr int LAST = N / 4;
+        const int blk = (int)blockIdx.x == LAST ? LAST : xcd_swizzle((int)blockIdx.x, LAST);
+        if (blk != 0 && blk != LAST) {
+            zpass_two_columns<N, T, P, H16, W16, ZNT, Z16>(a, smem, twr, tid, tile, 2 * blk);
+            return;
+        }
+        if (blk == LAST) { one_column(N / 2, 3); return; }
+        one_column(0, 3);
+        __syncthreads();            // the slowest wave is done with the FFT image before the next column's h~ overwrites it
+        one_column(1, 3);
+    } else {
+        int nb = (int)blockIdx.x, batches = 3;
+        if (ZC == 2 && nb >= a.zfull) { const int r = nb - a.zfull; nb = a.zfull + (r >> 1); batches = 1 + (r & 1); }
+#if OCEAN_ZTILE
+        else nb = xcd_swizzle(nb, a.zfull);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
+#endif
+        one_column(nb, batches);
+    }
 }
 
 // resident z-pass workgroups per CU (lower bound from LDS, threads and the register cap of the launch bounds)
@@ -734,9 +915,9 @@ template <int N, int T> constexpr int zpass_blocks_per_cu()
     return (by_regs >= 1 && by_regs < m) ? by_regs : (m < 1 ? 1 : m);
 }
 
-template <int N> constexpr size_t zpass_lds_bytes()
+template <int N, int ZW = 1> constexpr size_t zpass_lds_bytes()
 {
-    return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * 2 * N;
+    return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * (1 + ZW) * N;
 }
 
 // ---- x-pass helpers ------------------------------------------------------------------

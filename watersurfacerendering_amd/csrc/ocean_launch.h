@@ -34,7 +34,9 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     const unsigned tiles = c->tiles;
     hipError_t e;
     constexpr int C = G::CC;
-    constexpr size_t lds_rows = zpass_lds_bytes<N>();
+    constexpr size_t lds_rows = zpass_lds_bytes<N, 1>();
+    constexpr bool HAS2 = zpass_has_width2<N>();
+    constexpr size_t lds_rows2 = zpass_lds_bytes<N, 2>();
     constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
@@ -42,7 +44,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     if (c->attr_n != (uint32_t)N) {
-#define OCEAN_ALLOW_Z(h16, w16, znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, lds_rows)) != hipSuccess) return e;
+#define OCEAN_ALLOW_Z(h16, w16, znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, lds_rows)) != hipSuccess) return e; \
+        if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16, 2>, lds_rows2)) != hipSuccess) return e;
 #define OCEAN_ALLOW_Z4(h16, w16) OCEAN_ALLOW_Z(h16, w16, false, false) OCEAN_ALLOW_Z(h16, w16, true, false) OCEAN_ALLOW_Z(h16, w16, false, true) OCEAN_ALLOW_Z(h16, w16, true, true)
         OCEAN_ALLOW_Z4(false, false) OCEAN_ALLOW_Z4(true, false) OCEAN_ALLOW_Z4(false, true) OCEAN_ALLOW_Z4(true, true)
 #undef OCEAN_ALLOW_Z4
@@ -72,10 +75,14 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     arm(0);
 #endif
     {
-        unsigned gx = N / 2 + 1;
+        // two neighbouring columns per workgroup (k_zpass<..., 2>): 4096^2 always, from 1024 up when the intermediates are streamed
+        static const char* const zw_env = getenv("OCEAN_ZW");                   // developer override (A/B runs): 1 or 2
+        bool zw2 = HAS2 && (N == 4096 || (stream_maps & 4));
+        if (zw_env && HAS2) zw2 = atoi(zw_env) == 2 && (N == 4096 || (stream_maps & 4));
+        unsigned gx = zw2 ? N / 4 + 1 : N / 2 + 1;
         FrameArgs za = a;
         za.zfull = (int)gx;
-        if ((stream_maps & 16) && tiles == 1 && zpass_columns<N>() == 2) {
+        if ((stream_maps & 16) && tiles == 1 && zpass_columns<N>() == 2 && !zw2) {
             // serial frames: split the columns of the last, partially filled round over two workgroups each
             const unsigned slots = (unsigned)zpass_blocks_per_cu<N, G::T_ROWS>() * (unsigned)c->cu_count;
             const unsigned rest = gx % slots;
@@ -85,9 +92,11 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
+#define OCEAN_ZPASS2(h16, w16, znt, z16) \
+        do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16, 2>, grid, block, lds_rows2, st, marks, za); break; } } \
+             launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, grid, block, lds_rows, st, marks, za); } while (0)
 #define OCEAN_ZPASS(h16, w16, znt) \
-        do { if (stream_maps & 8) launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, true>, grid, block, lds_rows, st, marks, za); \
-             else launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, false>, grid, block, lds_rows, st, marks, za); } while (0)
+        do { if (stream_maps & 8) OCEAN_ZPASS2(h16, w16, znt, true); else OCEAN_ZPASS2(h16, w16, znt, false); } while (0)
         const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
         switch (variant) {
             case 0: OCEAN_ZPASS(false, false, false); break;
@@ -100,6 +109,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             default: OCEAN_ZPASS(true, true, true); break;
         }
 #undef OCEAN_ZPASS
+#undef OCEAN_ZPASS2
     }
 #ifdef OCEAN_STAMPS
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
