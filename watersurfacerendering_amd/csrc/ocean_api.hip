@@ -462,11 +462,13 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     if (c->inter_bits == 16) stream_maps |= 8;          // bit 3: half2 intermediates (kernel variant, not a store policy)
     if (pipe) {
         // what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the memory-side
-        // cache: beyond it the intermediates are streamed too (bit 2, see store_z).  Never for a serial frame: its x pass
-        // reads them right behind the z pass, and 64-byte streamed pieces cost the z pass more than they save
-        // (4096^2 serial: 325 vs 350 us; profiles/r02_layout_experiments.txt).
+        // cache: beyond it the intermediates are streamed too (bit 2, see store_z; the z pass then takes two columns per
+        // workgroup so that the streamed stores cover whole lines).  Never for a serial frame: its x pass reads them right
+        // behind the z pass (4096^2 serial 321-324 either way, 8 x 1024^2 serial 126 vs 136 us, depth 2 124 vs 114 us;
+        // 2048^2 depth 3 -- 243 MB -- 57-58 plain vs 59-60 streamed, depth 4 -- 310 MB -- 61 vs 58.5;
+        // profiles/r02_layout_experiments.txt).
         const double resident = texels * (10.0 + (c->inter_bits == 16 ? 8.0 : 16.0) * c->depth);
-        if (resident > 330.0e6) stream_maps |= 4;
+        if (resident > 300.0e6) stream_maps |= 4;
     }
     static const char* const split_env = getenv("OCEAN_ZSPLIT");                // developer override (A/B runs): 0 = never split
     if (!pipe && !(split_env && atoi(split_env) == 0)) stream_maps |= 16;       // this frame has the device to itself
