@@ -345,3 +345,30 @@ def test_readout_paths_under_pipelining_refer_to_the_last_frame():
     finally:
         W.host_unregister(pinned); W.host_unregister(staging)
     ref.close(); b.close()
+
+
+@pytest.mark.parametrize("n,tiles", [(64, 2048), (256, 160), (512, 40)])
+def test_streamed_variants_are_bit_identical_to_the_plain_ones(n, tiles):
+    """Big batches at depth 2 run the streamed instantiations of all three kernels (non-temporal map stores, streamed
+    intermediates); a synchronous call and a one-tile context run the plain ones.  Same frame, same bits: the kernels'
+    arithmetic is written so that no instantiation may round differently (constant multiplies of the butterflies as
+    instructions of their own, contraction off in the packing code) -- 256^2 in batches of 256 once differed by an ulp."""
+    b = make_batch(n, tiles=tiles, depth=2)
+    for j in range(3):
+        b.compute_waves_async(0.3 * j)
+    b.compute_waves_async(1.25)                      # streamed variants (8.4 M texels in flight twice: beyond the cache)
+    b.synchronize()
+    d2, q2 = b.read_maps()
+    h2 = [b.heights(i) for i in (0, tiles - 1)]
+    b.set_pipeline_depth(1)
+    b.compute_waves(1.25)                            # plain intermediates, maps streamed or not by size
+    d1, q1 = b.read_maps()
+    assert np.array_equal(d1, d2) and np.array_equal(q1, q2)
+    assert h2 == [b.heights(i) for i in (0, tiles - 1)]
+    b.close()
+    for i in (0, tiles // 2, tiles - 1):             # and a context of one tile (plain everything)
+        s = make_batch(n, tiles=1, depth=1, seed=SEED + i)
+        s.compute_waves(1.25)
+        ds, qs = s.read_maps()
+        assert np.array_equal(ds[0], d2[i]) and np.array_equal(qs[0], q2[i]), i
+        s.close()

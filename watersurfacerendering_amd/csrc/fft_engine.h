@@ -81,6 +81,12 @@ __device__ __forceinline__ v2 pk_neg_add_i(v2 a)            // -a + i a = (-a.x 
     asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(d) : "v"(a));
     return d;
 }
+__device__ __forceinline__ v2 pk_mul(v2 a, v2 b)            // (a.x b.x, a.y b.y) -- as an instruction of its own: a product the compiler sees
+{                                                            // may or may not be fused with the butterfly's next add, instantiation by
+    v2 d;                                                    // instantiation, and the variants of a kernel must agree bit for bit
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ v2 pk_muli(v2 a)                 // i a = (-a.y, a.x)
 {
     v2 d;
@@ -144,13 +150,13 @@ template <> struct Dft<16> {
         const v2 hh = {h, h};
         const v2 w1 = {c1, s1}, w3 = {s1, c1}, w9 = {-c1, -s1};
         x[1 + 4] = pk_cmul(x[1 + 4], w1);                 // b=1,k1=1 : w^1
-        x[1 + 8] = pk_add_i(x[1 + 8], x[1 + 8]) * hh;     // b=1,k1=2 : w^2 = (1+i) h
+        x[1 + 8] = pk_mul(pk_add_i(x[1 + 8], x[1 + 8]), hh);     // b=1,k1=2 : w^2 = (1+i) h
         x[1 + 12] = pk_cmul(x[1 + 12], w3);               // b=1,k1=3 : w^3
-        x[2 + 4] = pk_add_i(x[2 + 4], x[2 + 4]) * hh;     // b=2,k1=1 : w^2
+        x[2 + 4] = pk_mul(pk_add_i(x[2 + 4], x[2 + 4]), hh);     // b=2,k1=1 : w^2
         x[2 + 8] = pk_muli(x[2 + 8]);                     // b=2,k1=2 : w^4 = i
-        x[2 + 12] = pk_neg_add_i(x[2 + 12]) * hh;         // b=2,k1=3 : w^6 = (-1+i) h
+        x[2 + 12] = pk_mul(pk_neg_add_i(x[2 + 12]), hh);         // b=2,k1=3 : w^6 = (-1+i) h
         x[3 + 4] = pk_cmul(x[3 + 4], w3);                 // b=3,k1=1 : w^3
-        x[3 + 8] = pk_neg_add_i(x[3 + 8]) * hh;           // b=3,k1=2 : w^6
+        x[3 + 8] = pk_mul(pk_neg_add_i(x[3 + 8]), hh);           // b=3,k1=2 : w^6
         x[3 + 12] = pk_cmul(x[3 + 12], w9);               // b=3,k1=3 : w^9
         // outer DFT4 over b for each k1; result k2 lands at index k1 + 4*k2
 #pragma unroll

@@ -1088,6 +1088,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     [[maybe_unused]] const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
     c32 held[LS::IT][LS::RL];
     auto emit = [&](int p, int c, c32 slopes, c32 derivs) {
+#pragma clang fp contract(off)          // every instantiation of this kernel rounds alike: frames are bit-identical whichever one a launch picks
         const int q = u0 + c;
         if (q > N / 2) return;                                      // padding row
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
@@ -1199,6 +1200,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
     auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z0, nf, u0 + c, -1.0f, uu); };
     auto out = [&](int p, int c, c32 v, int u, int i) {
+#pragma clang fp contract(off)          // as in k_xpass_b
         const int q = u0 + c;
         if (q > N / 2) return;
         const float s = ((p + q) & 1) ? -1.0f : 1.0f;
