@@ -457,13 +457,14 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
 // Interleaved transforms per z-pass batch: 2 (two batches: {pair 0, pair 1}, {pair 2, height}) or 4 (all of a
 // column's transforms in ONE batch with twice the threads).  Four at once halves the dependent chain of a
 // workgroup -- stages, barriers, LDS round trips -- which is what a single small tile waits for: 512^2 z pass
-// 8.0 -> 6.9 us.  At 1024^2 it is slower (14.9 -> 16.5 us) and from 2048 up the two-batch form keeps three
+// 8.0 -> 6.9 us, 256^2 (one wave per column, whose two-transform batches fill half of it) 10.1 -> 8.4 us.
+// At 1024^2 it is slower (14.9 -> 16.5 us) and from 2048 up the two-batch form keeps three
 // workgroups per CU.  (The same idea for the normal-map role -- pairs 1 and 2 as one batch of 2 C columns -- was
 // measured 50-60 % slower at both sizes; profiles/r02_small_tile_experiments.txt.)
 #ifndef OCEAN_ZC4
 #define OCEAN_ZC4 1
 #endif
-template <int N> constexpr int zpass_columns() { return (OCEAN_ZC4 && N == 512) ? 4 : 2; }
+template <int N> constexpr int zpass_columns() { return (OCEAN_ZC4 && (N == 512 || N == 256)) ? 4 : 2; }
 // Spectrum columns per z-pass workgroup.  Two NEIGHBOURING columns (each batch = the same pair of both columns) make every
 // store instruction of the last stage cover whole 128-byte lines of the row-blocked intermediates (2 x 64-byte pieces side by
 // side) instead of half lines -- what the non-temporal stores of big tiles and batches need.  Costs N more floats of LDS (a
