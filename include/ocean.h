@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 1
+#define OCEAN_ABI_VERSION 2   /* 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips (additions only) */
 
 enum {
     OCEAN_OK            =  0,
