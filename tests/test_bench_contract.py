@@ -97,11 +97,11 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The roofline fractions of the committed default bench line (profiles/r02w_bench_default.json) can be recomputed from
-    the committed rocprofv3 summary (profiles/kernel_stats.json <- r02w_kernel_stats_2048_bench_depth1.csv) and the byte
+    """The roofline fractions of the committed default bench line (profiles/r02x_bench_default.json) can be recomputed from
+    the committed rocprofv3 summary (profiles/kernel_stats.json <- r02x_kernel_stats_2048_bench_depth1.csv) and the byte
     accounting of this file: every kernel within 6 %, nothing above 1, and the summaries regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    line = [l for l in open(os.path.join(prof, "r02w_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(prof, "r02x_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
@@ -117,7 +117,7 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r02w_kernel_stats_2048_bench_depth1.csv"))):
+    for row in csv.DictReader(open(os.path.join(prof, "r02x_kernel_stats_2048_bench_depth1.csv"))):
         m = re.search(r"(k_[a-z_]+)<2048", row["Name"])
         if m and m.group(1) in bench.KERNEL_BYTES_ACTUAL:
             a = acc.setdefault(m.group(1), [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
