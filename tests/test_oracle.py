@@ -291,3 +291,22 @@ def test_jacobian_golden_fixtures(path):
         assert np.abs(d[..., 3] - w).max() <= 2e-6 * np.abs(w).max()
         _, dn, _, _, _ = O.numpy_compute_waves(prep, float(t), lam=kw["lam"], jacobian=True)
         assert np.abs(dn[..., 3] - w).max() <= 1e-5 * np.abs(w).max()
+
+
+def test_dispersion_is_point_symmetric_bit_for_bit():
+    """omega(m, n) == omega((N-m)%N, (N-n)%N) exactly: k(N-i) = -k(i) in the reference's double-then-float evaluation
+    (WSTessendorf.cpp:76-79), so |k| and the quantised dispersion (.h:284-293) agree.  The HIP z pass relies on it: one
+    sincos animates a spectrum element and its point mirror."""
+    from oracle import oracle as O
+    for n, length, kw in [(16, 1000.0, {}), (64, 370.0, dict(wind_speed=12.0)), (256, 1000.0, {})]:
+        o = O.Oracle(n, length, **kw)
+        o.prepare(seed=3)
+        om = np.array(o.omega)
+        idx = (n - np.arange(n)) % n
+        assert np.array_equal(om, om[np.ix_(idx, idx)])
+    for disp, param in ((1, 40.0), (2, 1000.0)):          # the two relations the reference defines but never calls
+        o = O.Oracle(64, dispersion=(disp, param))
+        o.prepare(seed=3)
+        om = np.array(o.omega)
+        idx = (64 - np.arange(64)) % 64
+        assert np.array_equal(om, om[np.ix_(idx, idx)])

@@ -405,6 +405,57 @@ __device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
     return height_re(h0r, h0i, c, s);
 }
 
+// ---- phase 1 of the z pass: animate a spectrum column and its point mirror -----------------------------------------------
+// The quantised dispersion is point-symmetric bit for bit -- omega(m, n) == omega((N-m)%N, (N-n)%N): k(N-i) = -k(i) exactly, so
+// |k| and everything computed from it agree (tests/test_oracle.py checks the array) -- and the z pass always needs element
+// e of column nb TOGETHER with element (N-e)%N of the mirror column (N-nb)%N (S+- = (a +- b)/2).  One sincos therefore serves
+// both: half the sincos and half the dispersion reads of animating the two columns separately, and S+, S-(0) are formed in
+// the registers that hold a and b (no staging of h~ in LDS, one barrier less).  Items are element PAIRS (n, n+1), n even.
+template <int N, bool H16, bool W16>
+__device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
+                                                float4& ha, float2& hb0, float2& hb1, float2& w)
+{
+    const size_t n2 = (size_t)N * N;
+    const int mcol = (N - col) & (N - 1);
+    const size_t g = (size_t)col * N + n;
+    const size_t m0 = (size_t)mcol * N + ((N - n) & (N - 1)), m1 = (size_t)mcol * N + (N - n - 1);
+#ifdef OCEAN_ABL_NOLOAD
+    ha = make_float4(1.f + g, 2.f, 3.f, 4.f); hb0 = make_float2(0.5f, 1.5f); hb1 = make_float2(2.5f, 3.5f); w = make_float2(0.5f, 0.25f);
+    return;
+#endif
+    if constexpr (H16) {
+        const __half2* __restrict__ hh = a.h0h + tile * n2;
+        const float2 raw2 = *reinterpret_cast<const float2*>(hh + g);       // two half2
+        const __half2 x0 = *reinterpret_cast<const __half2*>(&raw2.x), x1 = *reinterpret_cast<const __half2*>(&raw2.y);
+        const float2 f0 = __half22float2(x0), f1 = __half22float2(x1), g0 = __half22float2(hh[m0]), g1 = __half22float2(hh[m1]);
+        ha = make_float4(f0.x * h16s, f0.y * h16s, f1.x * h16s, f1.y * h16s);
+        hb0 = make_float2(g0.x * h16s, g0.y * h16s); hb1 = make_float2(g1.x * h16s, g1.y * h16s);
+    } else {
+        const float2* __restrict__ h0 = a.h0 + tile * n2;
+        ha = *reinterpret_cast<const float4*>(h0 + g);
+        hb0 = h0[m0]; hb1 = h0[m1];
+    }
+    if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
+        const unsigned two = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
+        w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+    } else {
+        w = *reinterpret_cast<const float2*>(a.omega + tile * n2 + g);
+    }
+}
+// h~ of the element (h0a) and of its mirror (h0b), which share the phase w t
+__device__ __forceinline__ void animate_with_mirror(float2 h0a, float2 h0b, float w, float t, float& av, float& bv)
+{
+    const float wt = mul_nocontract(w, t);      // ONE fp32 multiply, like the reference (.h:267)
+    float s, c;
+#ifdef OCEAN_ABL_SINCOS
+    s = wt * 1e-4f; c = 1.0f - s;
+#else
+    sincos_f32(wt, s, c);
+#endif
+    av = height_re(h0a.x, h0a.y, c, s);
+    bv = height_re(h0b.x, h0b.y, c, s);
+}
+
 // ---- half-spectrum storage geometry -------------------------------------------
 #ifndef OCEAN_ZTILE
 #define OCEAN_ZTILE 8          // rows per block of the intermediates (fp32: 64-byte pieces)
@@ -638,68 +689,40 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     float* sp0 = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());   // S+ of column nb0, of column nb0 + 1
     float* sp1 = sp0 + N;
     float* kzt = sp1 + N;
-    float* raw = reinterpret_cast<float*>(fbuf);                           // h~ of columns nb0, nb0+1, N-nb0, N-nb0-1 (16 N of the 17 N bytes)
-    const size_t n2 = (size_t)N * N;
-    const float2* __restrict__ h0 = a.h0 + tile * n2;
-    const float* __restrict__ om = a.omega + tile * n2;
+    float* raw = reinterpret_cast<float*>(fbuf);                           // [0], [1]: S-(0) of the two columns, until the first exchange
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
-    [[maybe_unused]] const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
-    [[maybe_unused]] const float base = W16 ? a.base_freq[tile] : 0.0f;
-    [[maybe_unused]] const uint16_t* __restrict__ oq = a.omega_q + tile * n2;
-    {
-        constexpr int ELEMS = 2 * N;                  // 4 columns * N/2 element pairs
-        constexpr int P1 = ELEMS / T;
-        constexpr int PB = P1 > 4 ? 4 : P1;
-        static_assert(ELEMS % T == 0 && P1 % PB == 0, "phase-1 batches");
+    const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
+    const float base = W16 ? a.base_freq[tile] : 0.0f;
+    {   // phase 1: columns nb0 and nb0 + 1, each with its mirror (zpass_load_pair)
+        constexpr int ITEMS = N;                      // 2 columns * N/2 element pairs
+        constexpr int P1 = ITEMS / T;
+        constexpr int PB = P1 > 2 ? 2 : P1;           // items in flight per thread (ten registers each; four spill under 2048's cap)
+        static_assert(ITEMS % T == 0 && P1 % PB == 0, "phase-1 batches");
 #pragma unroll 1
         for (int ub = 0; ub < P1; ub += PB) {
-            float4 hv[PB];
-            float2 wv[PB];
+            float4 ha[PB];
+            float2 hb0[PB], hb1[PB], wv[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int e = tid + (ub + u) * T;
-                const int s = e / (N / 2);
-                const int n = (e % (N / 2)) * 2;
-                const int col = (s & 2) ? ((N - nb0 - (s & 1)) & (N - 1)) : nb0 + (s & 1);
-                const size_t g = (size_t)col * N + n;
-                if constexpr (H16) {
-                    const float2 raw2 = *reinterpret_cast<const float2*>(a.h0h + tile * n2 + g);
-                    const __half2 ha = *reinterpret_cast<const __half2*>(&raw2.x);
-                    const __half2 hb = *reinterpret_cast<const __half2*>(&raw2.y);
-                    const float2 fa = __half22float2(ha), fb = __half22float2(hb);
-                    hv[u] = make_float4(fa.x * h16s, fa.y * h16s, fb.x * h16s, fb.y * h16s);
-                } else {
-                    hv[u] = *reinterpret_cast<const float4*>(h0 + g);
-                }
-                if constexpr (W16) {
-                    const unsigned two = *reinterpret_cast<const unsigned*>(oq + g);
-                    wv[u] = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
-                } else {
-                    wv[u] = *reinterpret_cast<const float2*>(om + g);
-                }
+                const int it = tid + (ub + u) * T;
+                zpass_load_pair<N, H16, W16>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int e = tid + (ub + u) * T;
-                const int s = e / (N / 2);
-                const int n = (e % (N / 2)) * 2;
-                float2 v;
-                v.x = animate(hv[u].x, hv[u].y, wv[u].x, t);
-                v.y = animate(hv[u].z, hv[u].w, wv[u].y, t);
-                *reinterpret_cast<float2*>(raw + s * N + n) = v;
+                const int it = tid + (ub + u) * T;
+                const int c = it / (N / 2), n = 2 * (it % (N / 2));
+                float a0, b0, a1, b1;
+                animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
+                animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
+                *reinterpret_cast<float2*>((c ? sp1 : sp0) + n) = make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
+                if (c == 0) *reinterpret_cast<float2*>(kzt + n) = *reinterpret_cast<const float2*>(k1 + n);
+                if (n == 0) raw[c] = 0.5f * (a0 - b0);
             }
         }
     }
     __syncthreads();
-    const float sm00 = 0.5f * (raw[0] - raw[2 * N]), sm01 = 0.5f * (raw[N] - raw[3 * N]);      // S-(0) of the two columns
-    for (int e = tid; e < N; e += T) {
-        const int me = (N - e) & (N - 1);
-        sp0[e] = 0.5f * (raw[e] + raw[2 * N + me]);
-        sp1[e] = 0.5f * (raw[N + e] + raw[3 * N + me]);
-        kzt[e] = k1[e];
-    }
-    __syncthreads();
+    const float sm00 = raw[0], sm01 = raw[1];      // S-(0) of the two columns
 
     [[maybe_unused]] float su = 1.0f, sk = 1.0f, s3 = 1.0f;
     float g3 = 1.0f;
@@ -777,8 +800,10 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 // spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
 // 1024 and 4096 would spill at that cap and keep the looser one
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
+// (two columns per workgroup at 2048: 59 KB of LDS allow two workgroups per CU, i.e. four waves per SIMD and 128 VGPRs; the
+//  80-VGPR cap of the one-column form would only make that variant spill)
 template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false, bool Z16 = false, int ZW = 1>
-__global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameArgs a)
+__global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ZC = zpass_columns<N>();
@@ -796,66 +821,42 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
     TwiddleRegs<N, ZC, T, P> twr;
     twr.load(a.tw, tid);
     auto one_column = [&](const int nb, const int batches) {
-    const int nbb = (N - nb) & (N - 1);
-    const size_t n2 = (size_t)N * N;
-    const float2* __restrict__ h0 = a.h0 + tile * n2;
-    const float* __restrict__ om = a.omega + tile * n2;
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;               // [N], cache-resident table
     const bool col0 = (nb == 0);
-    [[maybe_unused]] const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
-    [[maybe_unused]] const float base = W16 ? a.base_freq[tile] : 0.0f;
-    [[maybe_unused]] const uint16_t* __restrict__ oq = a.omega_q + tile * n2;
+    const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
+    const float base = W16 ? a.base_freq[tile] : 0.0f;
 
     OCEAN_STAMP(0);
-    // -- phase 1: animate columns nb and nbb; all loads issued before the first sincos
+    // -- phase 1: animate column nb with its mirror nbb (zpass_load_pair); all loads issued before the first sincos.
+    // S- is needed along the whole column only for the Nyquist column nb == 0 (Tx = S-); every other column needs just
+    // S-(0) (Tz at e == 0) and keeps the kz table in LDS instead.  The Nyquist column pairs with itself (nbb == 0): S+ is
+    // even and S- odd along e, so ONE array G(e) = h~(e, 0) carries both; every other column stores S+ directly.
     {
-        constexpr int ELEMS = N;                      // 2 columns * N/2 element pairs
-        constexpr int P1 = (ELEMS + T - 1) / T;
-        constexpr int PB = P1 > 4 ? 4 : P1;          // loads in flight per thread (8 was measured no better)
+        constexpr int PAIRS = N / 2;
+        constexpr int P1 = (PAIRS + T - 1) / T;
+        constexpr int PB = P1 > 4 ? 4 : P1;          // items in flight per thread
         static_assert(P1 % PB == 0, "phase-1 batches");
 #pragma unroll 1
         for (int ub = 0; ub < P1; ub += PB) {
-            float4 hv[PB];
-            float2 wv[PB];
+            float4 ha[PB];
+            float2 hb0[PB], hb1[PB], wv[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int e = tid + (ub + u) * T;
-                if (ELEMS % T == 0 || e < ELEMS) {
-                    const int s = e / (N / 2);
-                    const int n = (e % (N / 2)) * 2;
-                    const size_t g = (size_t)(s ? nbb : nb) * N + n;
-#ifdef OCEAN_ABL_NOLOAD
-                    hv[u] = make_float4(1.f + g, 2.f, 3.f, 4.f); wv[u] = make_float2(0.5f, 0.25f);
-#else
-                    if constexpr (H16) {
-                        const float2 raw2 = *reinterpret_cast<const float2*>(a.h0h + tile * n2 + g);   // two half2
-                        const __half2 ha = *reinterpret_cast<const __half2*>(&raw2.x);
-                        const __half2 hb = *reinterpret_cast<const __half2*>(&raw2.y);
-                        const float2 fa = __half22float2(ha), fb = __half22float2(hb);
-                        hv[u] = make_float4(fa.x * h16s, fa.y * h16s, fb.x * h16s, fb.y * h16s);
-                    } else {
-                        hv[u] = *reinterpret_cast<const float4*>(h0 + g);
-                    }
-                    if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
-                        const unsigned two = *reinterpret_cast<const unsigned*>(oq + g);
-                        wv[u] = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
-                    } else {
-                        wv[u] = *reinterpret_cast<const float2*>(om + g);
-                    }
-#endif
-                }
+                const int it = tid + (ub + u) * T;
+                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N, H16, W16>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int e = tid + (ub + u) * T;
-                if (ELEMS % T == 0 || e < ELEMS) {
-                    const int s = e / (N / 2);
-                    const int n = (e % (N / 2)) * 2;
-                    float2 v;
-                    v.x = animate(hv[u].x, hv[u].y, wv[u].x, t);
-                    v.y = animate(hv[u].z, hv[u].w, wv[u].y, t);
-                    *reinterpret_cast<float2*>(raw + s * N + n) = v;
+                const int it = tid + (ub + u) * T;
+                if (PAIRS % T == 0 || it < PAIRS) {
+                    const int n = 2 * it;
+                    float a0, b0, a1, b1;
+                    animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
+                    animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
+                    *reinterpret_cast<float2*>(sp + n) = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
+                    *reinterpret_cast<float2*>(kzt + n) = *reinterpret_cast<const float2*>(k1 + n);
+                    if (n == 0) raw[0] = 0.5f * (a0 - b0);          // S-(0), for everybody (the FFT image is not in use yet)
                 }
             }
         }
@@ -866,17 +867,7 @@ __global__ void __launch_bounds__(T, zpass_min_waves<N>()) k_zpass(const FrameAr
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
     }
     __syncthreads();
-    // S- is needed along the whole column only for the Nyquist column nb == 0 (Tx = S-);
-    // every other column needs just S-(0) (Tz at e == 0) and keeps the kz table in LDS instead.
-    // Nyquist column nb == 0 pairs with itself (nbb == 0): S+ is even and S- odd along e,
-    // so ONE array G(e) = h~(e, 0) carries both; every other column stores S+ directly.
-    const float sm0 = 0.5f * (raw[0] - raw[N]);
-    for (int e = tid; e < N; e += T) {
-        const float av = raw[e], bv = raw[N + ((N - e) & (N - 1))];
-        sp[e] = col0 ? av : 0.5f * (av + bv);
-        kzt[e] = k1[e];
-    }
-    __syncthreads();
+    const float sm0 = raw[0];
     OCEAN_STAMP(1);
 
     if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
