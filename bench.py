@@ -21,7 +21,7 @@ frames (also reported under extra).
 
 roofline: per-launch durations are the kernels' own execution times (events attached to the
 dispatches with hipExtLaunchKernelGGL on the launch stream, serial frames so that every kernel has
-the GPU to itself); bytes are what THIS pipeline has to move (74 B/texel: 24 / 28 / 22 per launch),
+the GPU to itself); bytes are what THIS pipeline has to move (73 B/texel: 23 / 28 / 22 per launch),
 with the PMC-measured traffic (profiles/traffic.json) and the rocprofv3 duration of the same
 kernel (profiles/kernel_stats.json) beside them.  SURVEY.md 8d's 108 B/texel figure is reported
 separately and labelled as a model, not traffic.
@@ -52,8 +52,8 @@ DT = 0.05
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 # Bytes per texel each launch of THIS pipeline has to move: half-size
 # intermediates, 16-bit dispersion.  roofline.achieved / frac use these.
-KERNEL_BYTES_ACTUAL = {"k_zpass": 24, "k_xpass_b": 28, "k_xpass_disp": 22}
-FRAME_BYTES_ACTUAL = 74.0
+KERNEL_BYTES_ACTUAL = {"k_zpass": 23, "k_xpass_b": 28, "k_xpass_disp": 22}
+FRAME_BYTES_ACTUAL = 73.0
 # SURVEY.md 8d's MODEL of a plain two-pass scheme with 3.5 full-size complex intermediates (no point
 # symmetry): 108 B/texel per frame.  Not the traffic of this pipeline; reported as `survey_model_*` only.
 KERNEL_BYTES_SURVEY = {"k_zpass": 40, "k_xpass_b": 40, "k_xpass_disp": 28}
@@ -336,9 +336,10 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
         "traffic_source": tr.get("source") if tr else None,
         "algorithmic_bytes_per_launch": d["own_bytes_per_launch"],
-        "bytes_model": "this pipeline's own algorithmic bytes per texel: k_zpass 24 (h0 8 + 16-bit dispersion 2 in, half-size "
+        "bytes_model": "this pipeline's own algorithmic bytes per texel: k_zpass 23 (h0 8 + 16-bit dispersion of HALF the columns 1 in -- a column "
+                       "and its point mirror share it --, half-size "
                        "intermediates 14 out), k_xpass_b 28 (10 in, raw height 2 + normal map 16 out), k_xpass_disp 22 (6 in, "
-                       "displacement map 16 out); 74 per frame (DESIGN.md section 5)",
+                       "displacement map 16 out); 73 per frame (DESIGN.md section 5)",
         "launch_us": d["launch_us"],
         "launch_us_source": "hipExtLaunchKernelGGL start/stop events on the launch stream (kernel execution time), serial frames, "
                             "mean over the timed frames; rocprofv3 --kernel-trace --stats of the same command: profiles/kernel_stats.json",
@@ -353,7 +354,7 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
         "frame_bytes_per_texel": own_bytes_per_texel,
         "frame_GBps": frame_own / (ms_per_step * 1e-3) * 1e-9,
         "frame_frac": frame_own / (ms_per_step * 1e-3) * 1e-9 / HBM_PEAK_GBPS,
-        "frame_note": "frame_* = the timed (pipelined) region on this pipeline's 74 B/texel; part of that traffic is served by the "
+        "frame_note": "frame_* = the timed (pipelined) region on this pipeline's 73 B/texel; part of that traffic is served by the "
                       "256 MiB Infinity Cache, so it is a rate of algorithmic bytes, bounded by what that mix can reach (DESIGN.md section 6)",
         "survey_model": {"what": "SURVEY.md 8d MODEL of a plain 3.5-transform two-pass scheme (108 B/texel; 40 / 40 / 28 per launch): "
                                  "model bytes divided by measured time -- NOT this pipeline's traffic, may exceed any physical rate",
@@ -622,7 +623,7 @@ def main():
             extra["1024x1024_batch8_per_gpu_share_of_config5"] = measure_config(W, 1024, 8, local_rank, 500, 150)
             extra["1024x1024_batch8_per_gpu_share_of_config5_depth2"] = measure_config(W, 1024, 8, local_rank, 500, 150, depth=2)
             extra["4096x4096_fp32_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3)
-            # BASELINE config 4's reduced-precision mode: half2 intermediates between the passes (60 instead of 74 B/texel;
+            # BASELINE config 4's reduced-precision mode: half2 intermediates between the passes (59 instead of 73 B/texel;
             # maps within 1e-3 of the fp32 path's, tests/test_parity_gpu.py) -- NOT the headline, which is fp32 throughout
             extra["4096x4096_fp16_intermediates_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3, inter_bits=16)
             extra["2048x2048_fp16_intermediates_depth3"] = measure_config(W, 2048, 1, local_rank, 1000, 300, depth=3, inter_bits=16)

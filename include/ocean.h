@@ -174,7 +174,7 @@ int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
  *                         displacement.w = (1 + l dDx/dx)(1 + l dDz/dz) - (l dDx/dz)(l dDz/dx),   l = lambda,
  *                       the Jacobian of the horizontal displacement, instead of the constant 1; the reference's
  *                       shaders already carry it (WaterSurfaceMesh.vert:29) and paint foam where it is negative
- *                       (WaterSurfaceMesh.frag:210-212).  86 instead of 74 bytes per texel.                  */
+ *                       (WaterSurfaceMesh.frag:210-212).  85 instead of 73 bytes per texel.                  */
 enum { OCEAN_MODE_FULL7 = 0, OCEAN_MODE_CHOPPY5 = 1, OCEAN_MODE_HEIGHT1 = 2, OCEAN_MODE_JACOBIAN = 3 };
 int ocean_set_mode(ocean_t* ctx, int mode);
 
@@ -196,7 +196,7 @@ int ocean_set_spectrum_precision(ocean_t* ctx, int bits);
 /* Precision of the intermediates between the two passes: 32 (default) or 16.  With 16 the z-axis pass stores its
  * outputs as half2, scaled per tile by a power of two chosen at ocean_prepare from a time-independent bound of the
  * spectrum's column sums (nothing can overflow), and the x-axis pass reads them back: 7 instead of 14 bytes per
- * texel each way (60 instead of 74 per frame).  This is BASELINE.json config 4's reduced-precision mode: the
+ * texel each way (59 instead of 73 per frame).  This is BASELINE.json config 4's reduced-precision mode: the
  * maps then differ from the fp32 path by up to ~1e-3 of a channel's maximum (tests state the measured bound);
  * the default fp32 path keeps its 1e-5.  Takes effect at the next ocean_prepare.                                  */
 int ocean_set_intermediate_precision(ocean_t* ctx, int bits);
@@ -311,8 +311,8 @@ int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
 const char* ocean_kernel_name(const ocean_t* ctx, int idx);
 
 /* HBM bytes per texel this pipeline has to move for one seven-field frame at the context's
- * precision settings (74 with the fp32 spectrum: 10 in, 14 + 14 half-size intermediates out
- * and in, 2 + 2 raw height, 32 maps).  SURVEY.md section 8d prices a plain 3.5-transform
+ * precision settings (73 with the fp32 spectrum: 8 + 1 in -- the 16-bit dispersion is read for half of the columns, a
+ * column and its point mirror share it --, 14 + 14 half-size intermediates out and in, 2 + 2 raw height, 32 maps).  SURVEY.md section 8d prices a plain 3.5-transform
  * two-pass scheme at 108; bench.py reports that figure separately, labelled as a model.     */
 int ocean_algorithmic_bytes_per_texel(const ocean_t* ctx);
 

@@ -25,7 +25,7 @@ def test_defaults_are_one_gpu_and_bounded(bench):
 
 def test_byte_accounting(bench):
     # this pipeline's own bytes are what roofline.achieved uses ...
-    assert sum(bench.KERNEL_BYTES_ACTUAL.values()) == bench.FRAME_BYTES_ACTUAL == 74
+    assert sum(bench.KERNEL_BYTES_ACTUAL.values()) == bench.FRAME_BYTES_ACTUAL == 73
     # ... SURVEY.md 8d's model is kept beside it: 12 (h0 + omega) + 16 * 3.5 (intermediates out and in) + 32 (maps) + 8
     assert bench.FRAME_BYTES_SURVEY == 12 + 16 * 3.5 + 32 + 8 == 108
     assert sum(bench.KERNEL_BYTES_SURVEY.values()) == 108
@@ -36,10 +36,10 @@ def test_byte_accounting(bench):
 def test_roofline_object_uses_own_bytes_and_never_exceeds_peak_on_them(bench):
     names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
     n2 = 2048 * 2048
-    r = bench.roofline_object(2048, 1, names, [0.027, 0.029, 0.0205], [0.06, 0.05, 0.04], 3, 0.054, 77.0, 74.0)
+    r = bench.roofline_object(2048, 1, names, [0.027, 0.029, 0.0205], [0.06, 0.05, 0.04], 3, 0.054, 77.0, 73.0)
     assert r["kernel"] == "k_xpass_b" and r["algorithmic_bytes_per_launch"] == 28 * n2
     assert r["achieved"] == pytest.approx(28 * n2 / 29e-6 * 1e-9) and r["frac"] == pytest.approx(r["achieved"] / 8000.0)
-    assert r["frame_frac"] == pytest.approx(74 * n2 / 54e-6 * 1e-9 / 8000.0) and r["frame_frac"] < 1.0
+    assert r["frame_frac"] == pytest.approx(73 * n2 / 54e-6 * 1e-9 / 8000.0) and r["frame_frac"] < 1.0
     assert "MODEL" in r["survey_model"]["what"] and "frac" not in r["survey_model"]       # the 108 figure is never a fraction of peak
     assert set(r["kernels"]) == set(names)
 
@@ -97,11 +97,11 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The roofline fractions of the committed default bench line (profiles/r02x_bench_default.json) can be recomputed from
-    the committed rocprofv3 summary (profiles/kernel_stats.json <- r02x_kernel_stats_2048_bench_depth1.csv) and the byte
+    """The roofline fractions of the committed default bench line (profiles/r02y_bench_default.json) can be recomputed from
+    the committed rocprofv3 summary (profiles/kernel_stats.json <- r02y_kernel_stats_2048_bench_depth1.csv) and the byte
     accounting of this file: every kernel within 6 %, nothing above 1, and the summaries regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    line = [l for l in open(os.path.join(prof, "r02x_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(prof, "r02y_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
@@ -117,7 +117,7 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r02x_kernel_stats_2048_bench_depth1.csv"))):
+    for row in csv.DictReader(open(os.path.join(prof, "r02y_kernel_stats_2048_bench_depth1.csv"))):
         m = re.search(r"(k_[a-z_]+)<2048", row["Name"])
         if m and m.group(1) in bench.KERNEL_BYTES_ACTUAL:
             a = acc.setdefault(m.group(1), [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])

@@ -966,11 +966,11 @@ const char* ocean_kernel_name(const ocean_t* c, int idx)
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {
     // what THIS pipeline has to move per texel in the seven-field fp32 mode (ocean_kernels.h):
-    // 8 (h0) + 2 (16-bit dispersion; 4 when the fp32 array is needed) + 14 + 14 (half-size intermediates out and
-    // in) + 2 + 2 (raw height) + 32 (maps).  SURVEY.md 8d's model of a plain 3.5-transform two-pass scheme is 108.
-    if (!c) return 74;
-    // OCEAN_MODE_JACOBIAN: the height plane becomes a full pair (+2 +2) and three more half-size real planes go out and in (+3*(2+2) - 4 for the hraw already counted) = +12
-    return 74 + (c->prepared && !c->omega16 ? 2 : 0) - (c->h0_bits == 16 ? 4 : 0) - (c->inter_bits == 16 ? 14 : 0) + (c->mode == OCEAN_MODE_JACOBIAN ? (c->inter_bits == 16 ? 10 : 12) : 0);
+    // 8 (h0) + 1 (16-bit dispersion of the columns 0..N/2 only: a column and its point mirror share it; 2 when the fp32
+    // array is needed) + 14 + 14 (half-size intermediates out and in) + 2 + 2 (raw height) + 32 (maps).  SURVEY.md 8d's
+    // model of a plain 3.5-transform two-pass scheme is 108.
+    if (!c) return 73;
+    return 73 + (c->prepared && !c->omega16 ? 1 : 0) - (c->h0_bits == 16 ? 4 : 0) - (c->inter_bits == 16 ? 14 : 0) + (c->mode == OCEAN_MODE_JACOBIAN ? (c->inter_bits == 16 ? 10 : 12) : 0);
 }
 
 }  // extern "C"

@@ -16,7 +16,8 @@
 //      the oracle: tests/test_oracle.py::test_reference_output_point_symmetry.)
 //
 //   k_zpass      one spectrum column nb (kx index) in [0, N/2] per workgroup: animate
-//                columns nb and -nb (contiguous runs of the transposed spectrum),
+//                columns nb and -nb (contiguous runs of the transposed spectrum; an element and
+//                its point mirror share their phase, hence one sincos and one dispersion read),
 //                S+ = (a+b)/2, S- = (a-b)/2, build the three packed pairs and the height
 //                from S+/S- and the wave-vector coefficients, four z-axis inverse FFTs.
 //   k_xpass_b    x-axis pass, part 1, one launch, two kinds of workgroup: HEIGHT (two
@@ -26,10 +27,10 @@
 //   k_xpass_disp part 2, needs the min/max: pair 0 + raw height -> displacement-map rows.
 //   The x axis goes last so that every map row is written as whole contiguous lines.
 //
-// HBM bytes per texel actually moved (this pipeline): 10 (h0 8, dispersion as a 16-bit multiple
-// of the base frequency 2) + 14 + 14 (half-size intermediates out and in) + 2 + 2 (raw height)
-// + 32 (maps) = 74, against 108 for the straightforward 3.5-transform two-pass scheme SURVEY.md
-// section 8d models.  60 with half2 intermediates (Z16 kernels), 86 in the Jacobian mode (JAC kernels:
+// HBM bytes per texel actually moved (this pipeline): 9 (h0 8, dispersion as a 16-bit multiple
+// of the base frequency, read for half of the columns: 1) + 14 + 14 (half-size intermediates out and in)
+// + 2 + 2 (raw height) + 32 (maps) = 73, against 108 for the straightforward 3.5-transform two-pass scheme
+// SURVEY.md section 8d models.  59 with half2 intermediates (Z16 kernels), 85 in the Jacobian mode (JAC kernels:
 // the height plane becomes pair 3 = (height, cross derivative), and two more half-size real planes
 // carry the Jacobian's factors to the displacement pass).
 #pragma once
@@ -391,18 +392,6 @@ __device__ __forceinline__ float height_re(float h0r, float h0i, float c, float 
 #pragma clang fp contract(off)
     const float re = h0r * c - h0i * s;
     return re + re;
-}
-
-__device__ __forceinline__ float animate(float h0r, float h0i, float w, float t)
-{
-    const float wt = mul_nocontract(w, t);      // ONE fp32 multiply, like the reference (.h:267)
-    float s, c;
-#ifdef OCEAN_ABL_SINCOS
-    s = wt * 1e-4f; c = 1.0f - s;
-#else
-    sincos_f32(wt, s, c);
-#endif
-    return height_re(h0r, h0i, c, s);
 }
 
 // ---- phase 1 of the z pass: animate a spectrum column and its point mirror -----------------------------------------------
@@ -810,7 +799,7 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // ZC interleaved transforms
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, ZC>());   // S+ [N]
     float* kzt = sp + N;                                                   // kz table [N]
-    float* raw = reinterpret_cast<float*>(fbuf);                           // h~ columns nb, nbb (before the FFTs)
+    float* raw = reinterpret_cast<float*>(fbuf);                           // [0]: S-(0) of the column, until the first exchange
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
