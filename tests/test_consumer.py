@@ -184,4 +184,13 @@ def test_mip_chain_matches_oracle(n, tiles, tile):
     dl2, _ = b.build_mips(tile)
     disp2, _ = b.read_maps()
     assert np.array_equal(dl2[0], C.mip_chain(disp2[tile])[0])
+    # SetTileSize: the chain follows the new size (its buffers are re-allocated on the next build)
+    if n >= 64:
+        b.set_tile_size(n // 2)
+        b.prepare(0x5EED0000 + n)
+        b.compute_waves(0.75)
+        disp3, nrm3 = b.read_maps()
+        dl3, ql3 = b.build_mips(tile)
+        for got, want in zip(dl3 + ql3, C.mip_chain(disp3[tile]) + C.mip_chain(nrm3[tile])):
+            assert got.shape == want.shape and np.array_equal(got, want)
     b.close()
