@@ -77,7 +77,7 @@ public:
         m_Params.tile_length = tileLength;
         Push();
     }
-    ~WSTessendorf() { Unpin(); ocean_destroy(m_Ctx); }
+    ~WSTessendorf() { if (m_Pending) (void)ocean_synchronize(m_Ctx); Unpin(); ocean_destroy(m_Ctx); }
     WSTessendorf(const WSTessendorf&) = delete;
     WSTessendorf& operator=(const WSTessendorf&) = delete;
 
@@ -89,31 +89,67 @@ public:
     }
     void Prepare(uint64_t seed, const float* gaussRandomOrNull = nullptr)
     {
+        if (m_Pending) Wait();
         Check(ocean_prepare(m_Ctx, seed, gaussRandomOrNull), "ocean_prepare");
         const size_t n = ocean_tile_size(m_Ctx);
         Unpin();
-        m_Displacements.assign(n * n, Displacement(0.f, 0.f, 0.f, 0.f));     // .cpp:48-51
-        m_Normals.assign(n * n, Normal(0.f, 1.f, 0.f, 0.f));                 // .cpp:53-54
+        m_Front = 0;
+        m_Displacements[1].clear(); m_Normals[1].clear();                      // the back pair exists only once ComputeWavesAsync is used
+        m_Displacements[0].assign(n * n, Displacement(0.f, 0.f, 0.f, 0.f));    // .cpp:48-51
+        m_Normals[0].assign(n * n, Normal(0.f, 1.f, 0.f, 0.f));                // .cpp:53-54
         // page-lock the two host vectors so the per-frame read-out is a direct DMA (best effort:
         // a pageable vector still works, the copy is then staged by the runtime)
-        m_Pinned = ocean_host_register(m_Displacements.data(), n * n * sizeof(Displacement)) == OCEAN_OK;
-        if (m_Pinned && ocean_host_register(m_Normals.data(), n * n * sizeof(Normal)) != OCEAN_OK) {
-            ocean_host_unregister(m_Displacements.data());
-            m_Pinned = false;
-        }
+        m_Pinned[0] = Pin(0);
     }
 
     // WSTessendorf.cpp:284-455: returns the amplitude of the normalised heights
     float ComputeWaves(float time)
     {
+        if (m_Pending) Wait();
         float amp = 0.f;
         Check(ocean_compute_waves(m_Ctx, time, &amp), "ocean_compute_waves");
-        Check(ocean_read_maps(m_Ctx, 0, 1, reinterpret_cast<float*>(m_Displacements.data()),
-                              reinterpret_cast<float*>(m_Normals.data())), "ocean_read_maps");
+        Check(ocean_read_maps(m_Ctx, 0, 1, reinterpret_cast<float*>(m_Displacements[m_Front].data()),
+                              reinterpret_cast<float*>(m_Normals[m_Front].data())), "ocean_read_maps");
         float a;
         Check(ocean_get_heights(m_Ctx, 0, &a, &m_MinHeight, &m_MaxHeight), "ocean_get_heights");
         return amp;
     }
+
+    // Opt-in non-blocking pair, beyond the reference -- whose own note on its DOUBLE_BUFFERED switch says "should be on dedicated
+    // thread" (WaterSurfaceMesh.h:26-34): ComputeWaves above is synthesis + a blocking copy of both maps to the host, and the copy
+    // is 10-40 x the synthesis (213 us at 512^2, 2.5 ms at 2048^2).  ComputeWavesAsync enqueues the frame and the DMA of both maps
+    // into a BACK pair of host vectors and returns A as soon as the frame's kernels have finished (ocean_wait_frame: a poll of
+    // the frame's completion records) -- the copy is still in flight.  Wait() blocks until it has landed and makes that pair the
+    // front one.  In between, GetDisplacements() / GetNormals() / GetMinHeight() / GetMaxHeight() keep returning the previous
+    // frame, untouched: exactly what DOUBLE_BUFFERED does with its two texture pairs (WaterSurfaceMesh.cpp:187-199, 233-239).
+    float ComputeWavesAsync(float time)
+    {
+        if (m_Pending) Wait();
+        const int back = m_Front ^ 1;
+        const size_t n2 = m_Displacements[m_Front].size();
+        if (m_Displacements[back].size() != n2) {
+            m_Displacements[back].assign(n2, Displacement(0.f, 0.f, 0.f, 0.f));
+            m_Normals[back].assign(n2, Normal(0.f, 1.f, 0.f, 0.f));
+            m_Pinned[back] = Pin(back);
+        }
+        Check(ocean_compute_waves_async(m_Ctx, time), "ocean_compute_waves_async");
+        Check(ocean_read_maps_async(m_Ctx, 0, 1, reinterpret_cast<float*>(m_Displacements[back].data()),
+                                    reinterpret_cast<float*>(m_Normals[back].data())), "ocean_read_maps_async");
+        float amp = 0.f, a;
+        Check(ocean_wait_frame(m_Ctx, &amp), "ocean_wait_frame");
+        Check(ocean_get_heights(m_Ctx, 0, &a, &m_PendingMin, &m_PendingMax), "ocean_get_heights");
+        m_Pending = true;
+        return amp;
+    }
+    void Wait()
+    {
+        if (!m_Pending) return;
+        Check(ocean_synchronize(m_Ctx), "ocean_synchronize");
+        m_Front ^= 1;
+        m_MinHeight = m_PendingMin; m_MaxHeight = m_PendingMax;
+        m_Pending = false;
+    }
+    bool Pending() const { return m_Pending; }
 
     // Getters: WSTessendorf.h:82-107
     auto GetTileSize() const { return ocean_tile_size(m_Ctx); }
@@ -131,15 +167,16 @@ public:
     auto GetDisplacementLambda() const { return m_Params.lambda; }
     float GetMinHeight() const { return m_MinHeight; }
     float GetMaxHeight() const { return m_MaxHeight; }
-    size_t GetDisplacementCount() const { return m_Displacements.size(); }
-    const std::vector<Displacement>& GetDisplacements() const { return m_Displacements; }
-    size_t GetNormalCount() const { return m_Normals.size(); }
-    const std::vector<Normal>& GetNormals() const { return m_Normals; }
+    size_t GetDisplacementCount() const { return m_Displacements[m_Front].size(); }
+    const std::vector<Displacement>& GetDisplacements() const { return m_Displacements[m_Front]; }
+    size_t GetNormalCount() const { return m_Normals[m_Front].size(); }
+    const std::vector<Normal>& GetNormals() const { return m_Normals[m_Front]; }
 
     // Setters: WSTessendorf.cpp:459-505
     void SetTileSize(uint32_t size)
     {
         if (size == 0 || (size & (size - 1))) return;
+        if (m_Pending) Wait();
         Check(ocean_set_tile_size(m_Ctx, size), "ocean_set_tile_size");
     }
     void SetTileLength(float length) { m_Params.tile_length = length; Push(); }
@@ -158,12 +195,24 @@ public:
     ocean_t* Context() const { return m_Ctx; }
 
 private:
+    bool Pin(int i)
+    {
+        const size_t bytes = m_Displacements[i].size() * sizeof(Displacement);
+        if (ocean_host_register(m_Displacements[i].data(), bytes) != OCEAN_OK) return false;
+        if (ocean_host_register(m_Normals[i].data(), bytes) != OCEAN_OK) {
+            ocean_host_unregister(m_Displacements[i].data());
+            return false;
+        }
+        return true;
+    }
     void Unpin()
     {
-        if (!m_Pinned) return;
-        ocean_host_unregister(m_Displacements.data());
-        ocean_host_unregister(m_Normals.data());
-        m_Pinned = false;
+        for (int i = 0; i < 2; ++i) {
+            if (!m_Pinned[i]) continue;
+            ocean_host_unregister(m_Displacements[i].data());
+            ocean_host_unregister(m_Normals[i].data());
+            m_Pinned[i] = false;
+        }
     }
     void Push() { Check(ocean_set_params(m_Ctx, OCEAN_ALL_TILES, &m_Params), "ocean_set_params"); }
     static void Check(int rc, const char* what)
@@ -175,12 +224,15 @@ private:
 
     ocean_t* m_Ctx{ nullptr };
     ocean_params m_Params{};
-    std::vector<Displacement> m_Displacements;
-    std::vector<Normal> m_Normals;
+    std::vector<Displacement> m_Displacements[2];     // [m_Front]: what the getters return; the other pair: ComputeWavesAsync's target
+    std::vector<Normal> m_Normals[2];
+    int m_Front{ 0 };
+    bool m_Pending{ false };                          // a ComputeWavesAsync whose copy has not been waited for
+    float m_PendingMin{ -1.0f }, m_PendingMax{ 1.0f };
     float m_MinHeight{ -1.0f };     // WSTessendorf.h:227-228
     float m_MaxHeight{ 1.0f };
     uint64_t m_PrepareCount{ 0 };
-    bool m_Pinned{ false };
+    bool m_Pinned[2]{ false, false };
 };
 
 #endif  // WS_TESSENDORF_ADAPTOR_HPP_

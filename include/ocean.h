@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 2   /* 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips (additions only) */
+#define OCEAN_ABI_VERSION 3   /* 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
+                                 ocean_last_launch, ocean_export_maps (additions only) */
 
 enum {
     OCEAN_OK            =  0,
@@ -108,6 +109,16 @@ int ocean_prepare(ocean_t* ctx, uint64_t seed, const float* xi_or_null);
  *      ocean_set_time_offsets; tile i is evaluated at t + offset[i].             */
 int ocean_compute_waves(ocean_t* ctx, float t, float* out_amp);
 int ocean_compute_waves_async(ocean_t* ctx, float t);
+/* Waits for the most recently enqueued frame -- not for copies or gathers enqueued behind it -- and writes its height
+ * amplitudes to out_amp[tiles] (may be NULL).  ocean_compute_waves = ocean_compute_waves_async + ocean_wait_frame.
+ * The wait is a short poll of completion records the frame's last kernel leaves in host-coherent memory (no stream
+ * synchronisation, whose wake-up costs 13-16 us per call at the reference's call shape, WaterSurfaceMesh.cpp:145-154);
+ * after 2 ms of polling it falls back to hipStreamSynchronize.  When it returns, every workgroup of the frame has finished;
+ * whatever then reads the maps is ordered by the stream as always (read-out calls, ocean_stream, ocean_synchronize).
+ * With ocean_read_maps_async / ocean_read_maps_staging enqueued BEFORE the wait, the caller gets A while the DMA of the
+ * maps is still in flight: the reference's DOUBLE_BUFFERED idea (WaterSurfaceMesh.h:26-34) on the synthesis side;
+ * include/WSTessendorf.hpp: ComputeWavesAsync() / Wait().                                                                */
+int ocean_wait_frame(ocean_t* ctx, float* out_amp);
 int ocean_set_time_offsets(ocean_t* ctx, const float* offsets_or_null /* tiles */);
 int ocean_synchronize(ocean_t* ctx);
 
@@ -309,6 +320,31 @@ int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
 /* Name of the idx-th launch (0..2) of one frame, in the order ocean_time_frames reports
  * them: "k_zpass", "k_xpass_b", "k_xpass_disp" at every tile size.  NULL if idx is out of range. */
 const char* ocean_kernel_name(const ocean_t* ctx, int idx);
+
+/* What the most recent frame launched: the idx-th launch's (ocean_kernel_name order) tile size, grid, block and kernel
+ * variant.  The host picks a kernel instantiation per frame from the tile size, the precisions, the mode, the pipeline
+ * depth and the batch size (store policy, columns per z-pass workgroup, split last round); tests use this to prove that
+ * every variant the launcher can select has met the oracle (tests/test_variants_gpu.py).                              */
+enum {
+    OCEAN_LAUNCH_NT_MAPS         = 1,    /* x passes: maps stored non-temporally (template flag NTS)                    */
+    OCEAN_LAUNCH_NT_INTER        = 2,    /* z pass: intermediates stored non-temporally (ZNT)                           */
+    OCEAN_LAUNCH_HALF_INTER      = 4,    /* half2 intermediates (Z16), all three                                        */
+    OCEAN_LAUNCH_JACOBIAN        = 8,    /* OCEAN_MODE_JACOBIAN: x passes' JAC instantiations, z pass's pair-3 branch   */
+    OCEAN_LAUNCH_FP16_SPECTRUM   = 16,   /* z pass reads the half2 copy of h0 (wave-uniform branch, no instantiation)   */
+    OCEAN_LAUNCH_FP32_DISPERSION = 32,   /* z pass reads the fp32 dispersion array: some multiple of the base frequency
+                                            needs more than 16 bits (wave-uniform branch)                               */
+    OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64   /* z pass: the columns of the last, partially filled round of workgroups are
+                                            split over two workgroups each (serial frames of one tile)                  */
+};
+typedef struct ocean_launch_info {
+    uint32_t tile_size;
+    uint32_t grid_x, grid_y, block;
+    uint32_t lds_bytes;
+    uint32_t flags;            /* OCEAN_LAUNCH_*                                                                         */
+    uint32_t per_workgroup;    /* z pass: spectrum columns per workgroup (1 or 2); x passes: map rows per workgroup     */
+    uint32_t mode;             /* OCEAN_MODE_* of the frame                                                              */
+} ocean_launch_info;
+int ocean_last_launch(const ocean_t* ctx, int idx, ocean_launch_info* out);
 
 /* HBM bytes per texel this pipeline has to move for one seven-field frame at the context's
  * precision settings (73 with the fp32 spectrum: 8 + 1 in -- the 16-bit dispersion is read for half of the columns, a

@@ -46,6 +46,27 @@ int main(int argc, char** argv)
             std::fprintf(stderr, "adaptor_demo: N=%u ComputeWaves + read-out of both maps: %.1f us/frame\n",
                          model.GetTileSize(), us / frames);
         }
+        // optional fourth argument "async": the opt-in ComputeWavesAsync() / Wait() pair must deliver the same frame, keep the
+        // previous one readable in between, and return A before the copy has landed.  Prints "async <ok> <us to A> <us to maps>".
+        if (argc > 4 && std::strcmp(argv[4], "async") == 0) {
+            const float t2 = t + 2.0f;
+            const float prevFirst = model.GetDisplacements()[1].x, prevAmp = amp;
+            const auto t0 = std::chrono::steady_clock::now();
+            const float a2 = model.ComputeWavesAsync(t2);
+            const auto t1 = std::chrono::steady_clock::now();
+            bool ok = model.Pending() && model.GetDisplacements()[1].x == prevFirst;      // front pair untouched while the copy flies
+            model.Wait();
+            const auto t3 = std::chrono::steady_clock::now();
+            std::vector<WSTessendorf::Displacement> d2 = model.GetDisplacements();
+            std::vector<WSTessendorf::Normal> q2 = model.GetNormals();
+            const float mn2 = model.GetMinHeight(), mx2 = model.GetMaxHeight();
+            const float a3 = model.ComputeWaves(t2);                                      // the blocking call on the same time
+            ok = ok && a2 == a3 && a2 != prevAmp && mn2 == model.GetMinHeight() && mx2 == model.GetMaxHeight() &&
+                 std::memcmp(d2.data(), model.GetDisplacements().data(), dispBytes) == 0 &&
+                 std::memcmp(q2.data(), model.GetNormals().data(), nrmBytes) == 0;
+            std::printf("async %d %.1f %.1f\n", ok ? 1 : 0, std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                        std::chrono::duration<double, std::micro>(t3 - t0).count());
+        }
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "adaptor_demo: %s\n", e.what());

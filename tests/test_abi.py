@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(abi):
 
 def test_abi_version_defaults_and_strerror(abi):
     L = abi.lib()
-    assert L.ocean_abi_version() == 2
+    assert L.ocean_abi_version() == 3
     p = abi.Params()
     L.ocean_default_params(C.byref(p))
     # WSTessendorf.h:36-43,181

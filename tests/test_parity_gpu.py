@@ -366,8 +366,11 @@ def test_cpp_adaptor_matches_python_binding(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "adaptor_demo.cpp"), "-o", str(exe),
                     "-L", os.path.dirname(_abi.LIB_PATH), "-locean_hip", "-Wl,-rpath," + os.path.dirname(_abi.LIB_PATH),
                     "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    r = subprocess.run([str(exe), "128", "1.5"], capture_output=True, text=True, check=True)
-    n, amp, mn, mx, sd, sn = r.stdout.split()
+    r = subprocess.run([str(exe), "128", "1.5", "0", "async"], capture_output=True, text=True, check=True)
+    first, second = r.stdout.strip().splitlines()
+    n, amp, mn, mx, sd, sn = first.split()
+    tag, ok, us_amp, us_maps = second.split()       # ComputeWavesAsync() / Wait(): same frame as the blocking call, front pair untouched meanwhile
+    assert tag == "async" and ok == "1", second
     b = make_gpu(128, None, seed=42, wind=(1.0, 0.5), wind_speed=20.0, lam=-1.5)
     a = float(b.compute_waves(1.5)[0])
     d, q = b.read_maps()

@@ -103,6 +103,13 @@ class OceanBatch:
     def compute_waves_async(self, t: float):
         _abi.check(self._L.ocean_compute_waves_async(self._h, t), "ocean_compute_waves_async")
 
+    def wait_frame(self) -> np.ndarray:
+        """Amplitudes of the most recently enqueued frame once its last workgroup has finished (ocean_wait_frame: a poll of the
+        frame's completion records, not a stream synchronisation; copies enqueued behind the frame may still be running)."""
+        amp = np.empty(self.tiles, dtype=np.float32)
+        _abi.check(self._L.ocean_wait_frame(self._h, amp.ctypes.data_as(C.POINTER(C.c_float))), "ocean_wait_frame")
+        return amp
+
     def set_time_offsets(self, offsets):
         if offsets is None:
             _abi.check(self._L.ocean_set_time_offsets(self._h, None), "ocean_set_time_offsets")
@@ -266,6 +273,15 @@ class OceanBatch:
 
     def kernel_names(self):
         return [self._L.ocean_kernel_name(self._h, i).decode() for i in range(3)]
+
+    def last_launch(self):
+        """What the most recent frame launched: three dicts (ocean_launch_info) in kernel_names() order."""
+        out = []
+        for i in range(3):
+            li = _abi.LaunchInfo()
+            _abi.check(self._L.ocean_last_launch(self._h, i, C.byref(li)), "ocean_last_launch")
+            out.append({k: int(getattr(li, k)) for k, _ in _abi.LaunchInfo._fields_})
+        return out
 
     @property
     def algorithmic_bytes_per_texel(self) -> int:

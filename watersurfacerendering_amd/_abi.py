@@ -32,15 +32,18 @@ SYMBOLS = [
     "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_last_hip_error",
     "ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_set_lambda",
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
-    "ocean_compute_waves", "ocean_compute_waves_async", "ocean_set_time_offsets", "ocean_synchronize",
+    "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
     "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_bind_output",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
     "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
     "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
-    "ocean_time_frames", "ocean_kernel_name", "ocean_algorithmic_bytes_per_texel",
+    "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel",
 ]
+
+OCEAN_LAUNCH_NT_MAPS, OCEAN_LAUNCH_NT_INTER, OCEAN_LAUNCH_HALF_INTER, OCEAN_LAUNCH_JACOBIAN = 1, 2, 4, 8
+OCEAN_LAUNCH_FP16_SPECTRUM, OCEAN_LAUNCH_FP32_DISPERSION, OCEAN_LAUNCH_SPLIT_LAST_ROUND = 16, 32, 64
 
 
 class OceanError(RuntimeError):
@@ -56,8 +59,16 @@ class Params(C.Structure):
                 ("damping", C.c_float), ("lambda_", C.c_float)]
 
 
+class LaunchInfo(C.Structure):
+    """struct ocean_launch_info (include/ocean.h)."""
+    _fields_ = [("tile_size", C.c_uint32), ("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("block", C.c_uint32),
+                ("lds_bytes", C.c_uint32), ("flags", C.c_uint32), ("per_workgroup", C.c_uint32), ("mode", C.c_uint32)]
+
+
 def build(force: bool = False) -> str:
-    """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  force (or OCEAN_FORCE_REBUILD=1 in
+    the environment) rebuilds every translation unit from scratch instead of trusting file times."""
+    force = force or os.environ.get("OCEAN_FORCE_REBUILD", "") not in ("", "0")
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"))
     stale = (not os.path.exists(_BUILT_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_BUILT_LIB) for s in srcs)
@@ -106,6 +117,7 @@ def lib() -> C.CDLL:
         "ocean_prepare": (i32, [P, u64, C.c_void_p]),
         "ocean_compute_waves": (i32, [P, f32, FP]),
         "ocean_compute_waves_async": (i32, [P, f32]),
+        "ocean_wait_frame": (i32, [P, FP]),
         "ocean_set_time_offsets": (i32, [P, C.c_void_p]),
         "ocean_synchronize": (i32, [P]),
         "ocean_get_heights": (i32, [P, u32, FP, FP, FP]),
@@ -142,6 +154,7 @@ def lib() -> C.CDLL:
         "ocean_read_xi": (i32, [P, u32, C.c_void_p]),
         "ocean_time_frames": (i32, [P, f32, f32, i32, i32, FP, FP]),
         "ocean_kernel_name": (C.c_char_p, [P, i32]),
+        "ocean_last_launch": (i32, [P, i32, C.POINTER(LaunchInfo)]),
         "ocean_algorithmic_bytes_per_texel": (i32, [P]),
     }
     for name, (res, args) in sig.items():

@@ -4,6 +4,7 @@
 // file: without a usable device every entry point returns an error.
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -41,16 +42,19 @@ static void free_device(ocean_ctx* c)
     c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
     c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr; c->zscale = nullptr; c->zbounds = nullptr;
     c->prepared = false;
+    // nothing of the old buffers may be referred to any more: no frame, no chain to read out, no mips of the old size
+    c->have_frame = false; c->last_set = 0; c->frame_ctr = 0; c->mips_ready = false; c->grid_vertices = 0;
 }
 
 static void free_set(ocean_ctx* c, int i)
 {
-    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->jraw[i], c->jac0[i], c->minmax[i], c->dispN[i], c->nrmN[i]};
+    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->z3[i], c->jraw[i], c->jac0[i], c->minmax[i], c->done_ctr[i], c->dispN[i], c->nrmN[i]};
     for (void* b : per) if (b) (void)hipFree(b);
-    if (c->mm_host[i]) (void)hipHostFree(c->mm_host[i]);
+    if (c->done_rec[i]) (void)hipHostFree(c->done_rec[i]);
     for (auto& p : c->pack_half[i]) if (p) { (void)hipFree(p); p = nullptr; }
-    c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->jraw[i] = nullptr; c->jac0[i] = nullptr; c->minmax[i] = nullptr;
-    c->dispN[i] = nullptr; c->nrmN[i] = nullptr; c->mm_host[i] = nullptr;
+    c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->z3[i] = nullptr; c->jraw[i] = nullptr; c->jac0[i] = nullptr;
+    c->minmax[i] = nullptr; c->done_ctr[i] = nullptr; c->done_rec[i] = nullptr; c->seq[i] = 0;
+    c->dispN[i] = nullptr; c->nrmN[i] = nullptr;
 }
 
 static int alloc_set_buffers(ocean_ctx* c, int i)
@@ -58,24 +62,44 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
     // half-spectrum intermediates (ocean_kernels.h, struct Half): padded columns must read as zero
-    HIP_TRY(hipMalloc(&c->z[i], t * 4 * nu * 2 * nup * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->z[i], t * 3 * nu * 2 * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->zh[i], t * nu * nup * sizeof(float2)));
     HIP_TRY(hipMalloc(&c->hraw[i], t * nup * n * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->jraw[i], t * nup * n * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->jac0[i], t * nup * n * sizeof(float)));
     // zero-fill ON THE CHAIN'S OWN STREAM: the chain streams are non-blocking (no implicit ordering with the
     // null stream), and the first z pass of the chain is enqueued right behind this
-    HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 4 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
+    HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
     HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
     HIP_TRY(hipMemsetAsync(c->hraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
-    HIP_TRY(hipMemsetAsync(c->jraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
-    HIP_TRY(hipMemsetAsync(c->jac0[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
     HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
-    // the displacement pass also drops the final min/max keys into this host-coherent buffer, so the
-    // synchronous ComputeWaves needs one stream synchronisation and no device-to-host copy
-    HIP_TRY(hipHostMalloc((void**)&c->mm_host[i], t * 2 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipMalloc(&c->done_ctr[i], sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(c->done_ctr[i], 0, sizeof(unsigned), stream_of(c, i)));
+    // the last workgroup of a frame drops (min key, max key, sequence number) per tile into this host-coherent
+    // buffer: the synchronous ComputeWaves polls it -- no stream synchronisation, no device-to-host copy
+    HIP_TRY(hipHostMalloc((void**)&c->done_rec[i], t * sizeof(uint4), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->done_rec[i], 0, t * sizeof(uint4));
+    c->seq[i] = 0;
     HIP_TRY(hipMalloc(&c->dispN[i], t * n2 * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->nrmN[i], t * n2 * sizeof(float4)));
+    return OCEAN_OK;
+}
+
+// The three extra intermediates of OCEAN_MODE_JACOBIAN (+ 50 % of a chain's intermediates): allocated by the first frame
+// of that mode on the chain, so that contexts which never use the mode never pay for it.
+static int alloc_jacobian(ocean_ctx* c, int i)
+{
+    if (c->jac0[i]) return OCEAN_OK;               // the last of the three: complete
+    const size_t n = c->n, t = c->tiles;
+    const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
+    void** bufs[] = {(void**)&c->z3[i], (void**)&c->jraw[i], (void**)&c->jac0[i]};
+    const size_t bytes[] = {t * nu * 2 * nup * sizeof(float2), t * nup * n * sizeof(float), t * nup * n * sizeof(float)};
+    for (int k = 0; k < 3; ++k) {
+        if (*bufs[k]) { (void)hipFree(*bufs[k]); *bufs[k] = nullptr; }     // leftovers of an earlier failed attempt
+        if (hipMalloc(bufs[k], bytes[k]) != hipSuccess || hipMemsetAsync(*bufs[k], 0, bytes[k], stream_of(c, i)) != hipSuccess) {
+            for (int j = 0; j <= k; ++j) if (*bufs[j]) { (void)hipFree(*bufs[j]); *bufs[j] = nullptr; }
+            g_last_hip = (int)hipGetLastError();
+            return OCEAN_E_NOMEM;
+        }
+    }
     return OCEAN_OK;
 }
 
@@ -127,6 +151,7 @@ static int sync_all(ocean_ctx* c)
     if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
     if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
     for (bool& p : c->gather_pending) p = false;
+    c->consumer_pending = false;
     return OCEAN_OK;
 }
 #define SYNC_ALL(c) do { int rc_ = sync_all(c); if (rc_) return rc_; } while (0)
@@ -212,6 +237,7 @@ void ocean_destroy(ocean_t* c)
     if (c->mips_disp) (void)hipFree(c->mips_disp);
     if (c->mips_nrm) (void)hipFree(c->mips_nrm);
     if (c->grid_nrm) (void)hipFree(c->grid_nrm);
+    if (c->consumer_ev) (void)hipEventDestroy(c->consumer_ev);
     if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
     for (auto& row : c->mark_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
@@ -335,8 +361,9 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         SYNC_ALL(c);
         for (int i = 0; i < MAXD; ++i)
             if (c->z[i]) {
-                HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 4 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
+                HIP_TRY(hipMemsetAsync(c->z[i], 0, t * 3 * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
                 HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
+                if (c->z3[i]) HIP_TRY(hipMemsetAsync(c->z3[i], 0, t * nu * 2 * nup * sizeof(float2), stream_of(c, i)));
             }
         c->inter_bits_zeroed = c->inter_bits;
     }
@@ -379,8 +406,11 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     {
         unsigned overflow = 1;
         HIP_TRY(hipMemcpy(&overflow, c->omega_q_overflow, sizeof(unsigned), hipMemcpyDeviceToHost));
-        static const char* const w16_env = getenv("OCEAN_OMEGA16");             // developer override (A/B runs)
-        c->omega16 = overflow == 0 && !(w16_env && atoi(w16_env) == 0);
+        c->omega16 = overflow == 0;
+#ifdef OCEAN_DEVELOPER      // A/B builds only (make variant ... DEFS=-DOCEAN_DEVELOPER): the shipped library reads no environment
+        static const char* const w16_env = getenv("OCEAN_OMEGA16");
+        if (w16_env && atoi(w16_env) == 0) c->omega16 = false;
+#endif
     }
     c->seed = seed;
     c->prepared = true;
@@ -424,13 +454,20 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         HIP_TRY(hipStreamWaitEvent(st, c->gather_done[set], 0));
         c->gather_pending[set] = false;
     }
+    if (c->mode == OCEAN_MODE_JACOBIAN) {
+        int rc_ = alloc_jacobian(c, set);
+        if (rc_) return rc_;
+    }
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
     a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
-    a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set]; a.minmax = c->minmax[set];
-    a.minmax_host = c->mm_host[set];
+    a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
+    a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
+    a.done_rec = c->done_rec[set]; a.done_ctr = c->done_ctr[set];
+    if (++c->seq[set] == 0) c->seq[set] = 1;            // never 0: a fresh record buffer reads as "no frame"
+    a.frame_seq = c->seq[set];
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
     a.toff = c->use_toff ? c->toff : nullptr;
@@ -467,13 +504,21 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         // behind the z pass (4096^2 serial 321-324 either way, 8 x 1024^2 serial 126 vs 136 us, depth 2 124 vs 114 us;
         // 2048^2 depth 3 -- 243 MB -- 57-58 plain vs 59-60 streamed, depth 4 -- 310 MB -- 61 vs 58.5;
         // profiles/r02_layout_experiments.txt).
-        const double resident = texels * (10.0 + (c->inter_bits == 16 ? 8.0 : 16.0) * c->depth);
+        // (bytes per texel of a chain's intermediates: 14 of z / zh + 2 of raw height = 16, about 8 in the half2 form -- the
+        //  figures the threshold was measured with; the Jacobian mode's pair 3 (16 of z) and its three real planes (6) make
+        //  that 22, 14 in the half2 form)
+        const bool jac = c->mode == OCEAN_MODE_JACOBIAN;
+        const double inter = c->inter_bits == 16 ? (jac ? 14.0 : 8.0) : (jac ? 22.0 : 16.0);
+        const double resident = texels * (10.0 + inter * c->depth);
         if (resident > 300.0e6) stream_maps |= 4;
     }
-    static const char* const split_env = getenv("OCEAN_ZSPLIT");                // developer override (A/B runs): 0 = never split
-    if (!pipe && !(split_env && atoi(split_env) == 0)) stream_maps |= 16;       // this frame has the device to itself
-    static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // developer override (A/B runs): bit mask
+    if (!pipe) stream_maps |= 16;                                               // this frame has the device to itself
+#ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
+    static const char* const split_env = getenv("OCEAN_ZSPLIT");                // 0 = never split the last round
+    if (split_env && atoi(split_env) == 0) stream_maps &= ~16;
+    static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // bit mask of the store policies
     if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 24);
+#endif
     hipError_t e = hipErrorInvalidValue;
     if (c->n <= 256) e = ocean_launch_frame_small(c, a, stream_maps, st, marks);
     else if (c->n <= 1024) e = ocean_launch_frame_mid(c, a, stream_maps, st, marks);
@@ -504,13 +549,33 @@ int ocean_synchronize(ocean_t* c)
     return OCEAN_OK;
 }
 
-static int fetch_minmax(ocean_ctx* c, bool only_last_chain = false)
+// Waits until every workgroup of the chain's most recently enqueued frame has finished and copies its height keys to
+// c->h_minmax: a bounded poll of the completion records the frame's last workgroup writes into host-coherent memory
+// (ocean_kernels.h: frame_done), then -- the device is busy with something long, or shared -- a stream synchronisation.
+static int wait_frame(ocean_ctx* c, int set)
 {
-    // the keys of the last frame are in host-coherent memory once its stream has drained
-    if (only_last_chain) HIP_TRY(hipStreamSynchronize(stream_of(c, c->last_set)));
-    else SYNC_ALL(c);
-    if (!c->mm_host[c->last_set]) return OCEAN_E_NOT_READY;
-    std::memcpy(c->h_minmax, c->mm_host[c->last_set], c->tiles * 2 * sizeof(unsigned));
+    if (!c->have_frame || !c->done_rec[set] || c->seq[set] == 0) return OCEAN_E_NOT_READY;
+    const unsigned want = c->seq[set];
+    const volatile uint4* rec = c->done_rec[set];
+    using clock = std::chrono::steady_clock;
+    clock::time_point t0;
+    bool timed = false, synced = false;
+    unsigned spins = 0;
+    for (uint32_t i = 0; i < c->tiles; ++i) {
+        while (__atomic_load_n(&rec[i].z, __ATOMIC_ACQUIRE) != want) {
+            if (synced) { g_last_hip = (int)hipErrorUnknown; return OCEAN_E_HIP; }      // the stream has drained and the record is not there
+            __builtin_ia32_pause();
+            if ((++spins & 255u) == 0) {
+                if (!timed) { t0 = clock::now(); timed = true; }
+                else if (clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    HIP_TRY(hipStreamSynchronize(stream_of(c, set)));
+                    synced = true;
+                }
+            }
+        }
+        c->h_minmax[2 * i + 0] = rec[i].x;
+        c->h_minmax[2 * i + 1] = rec[i].y;
+    }
     return OCEAN_OK;
 }
 
@@ -522,17 +587,24 @@ static float amp_of(const ocean_ctx* c, uint32_t tile, float* mn_out, float* mx_
     return std::fmax(std::fabs(mn), std::fabs(mx));   // .cpp:448
 }
 
+int ocean_wait_frame(ocean_t* c, float* out_amp)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    const int rc = wait_frame(c, c->last_set);
+    if (rc) return rc;
+    if (out_amp)
+        for (uint32_t i = 0; i < c->tiles; ++i) out_amp[i] = amp_of(c, i, nullptr, nullptr);
+    return OCEAN_OK;
+}
+
 int ocean_compute_waves(ocean_t* c, float t, float* out_amp)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     int rc = enqueue_frame(c, t, true, nullptr);
     if (rc) return rc;
-    rc = fetch_minmax(c, true);        // waits for this frame's chain only
-    if (rc) return rc;
-    if (out_amp)
-        for (uint32_t i = 0; i < c->tiles; ++i) out_amp[i] = amp_of(c, i, nullptr, nullptr);
-    return OCEAN_OK;
+    return ocean_wait_frame(c, out_amp);        // waits for this frame only
 }
 
 int ocean_set_time_offsets(ocean_t* c, const float* offsets)
@@ -551,8 +623,8 @@ int ocean_get_heights(ocean_t* c, uint32_t tile, float* amp, float* min_h, float
 {
     if (!c || tile >= c->tiles) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = fetch_minmax(c);
+    if (!c->have_frame) return OCEAN_E_NOT_READY;
+    int rc = wait_frame(c, c->last_set);
     if (rc) return rc;
     const float a = amp_of(c, tile, min_h, max_h);
     if (amp) *amp = a;
@@ -562,7 +634,7 @@ int ocean_get_heights(ocean_t* c, uint32_t tile, float* amp, float* min_h, float
 int ocean_read_maps(ocean_t* c, uint32_t first, uint32_t count, float* disp, float* nrm)
 {
     if (!c || first >= c->tiles || count == 0 || first + count > c->tiles) return OCEAN_E_INVALID;
-    if (!c->prepared) return OCEAN_E_NOT_READY;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
     const float4* d = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + first * n2;
@@ -590,7 +662,7 @@ int ocean_host_unregister(void* host_ptr)
 int ocean_read_maps_async(ocean_t* c, uint32_t first, uint32_t count, float* disp, float* nrm)
 {
     if (!c || first >= c->tiles || count == 0 || first + count > c->tiles) return OCEAN_E_INVALID;
-    if (!c->prepared) return OCEAN_E_NOT_READY;
+    if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
     const float4* d = (c->ext_disp ? c->ext_disp : c->dispN[c->last_set]) + first * n2;
@@ -645,6 +717,29 @@ int ocean_bind_output(ocean_t* c, void* d_disp, void* d_nrm)
     return OCEAN_OK;
 }
 
+}  // extern "C"
+
+// The consumer kernels (vertex stage, mip chain) write context-wide output buffers and run on the stream of the frame they read.
+// At pipeline depth > 1 consecutive consumer calls land on different, mutually unordered chain streams: each call first makes
+// its stream wait for the previous consumer launch, so that two of them never write those buffers at once.
+static int consumer_begin(ocean_ctx* c, hipStream_t st)
+{
+    if (c->consumer_pending && c->consumer_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->consumer_ev, 0));
+    return OCEAN_OK;
+}
+static int consumer_end(ocean_ctx* c, hipStream_t st)
+{
+    if (!c->consumer_ev) HIP_TRY(hipEventCreateWithFlags(&c->consumer_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->consumer_ev, st));
+    c->consumer_stream = st;
+    c->consumer_pending = true;
+    return OCEAN_OK;
+}
+#define CONSUMER_BEGIN(c, st) do { int rc_ = consumer_begin(c, st); if (rc_) return rc_; } while (0)
+#define CONSUMER_END(c, st) do { int rc_ = consumer_end(c, st); if (rc_) return rc_; } while (0)
+
+extern "C" {
+
 int ocean_displace_grid(ocean_t* c, uint32_t tile, uint32_t grid_size, float vertex_distance, float uv_scale, float choppy)
 {
     if (!c || tile >= c->tiles || grid_size == 0 || grid_size > 8192) return OCEAN_E_INVALID;
@@ -669,8 +764,10 @@ int ocean_displace_grid(ocean_t* c, uint32_t tile, uint32_t grid_size, float ver
     g.n = (int)c->n; g.grid = (int)grid_size;
     g.vertex_distance = vertex_distance; g.uv_scale = uv_scale; g.choppy = choppy;
     // ordered after the frame that wrote these maps
+    CONSUMER_BEGIN(c, stream_of(c, c->last_set));
     hipLaunchKernelGGL(k_displace_grid, dim3((verts + 255) / 256), dim3(256), 0, stream_of(c, c->last_set), g);
     HIP_TRY(hipGetLastError());
+    CONSUMER_END(c, stream_of(c, c->last_set));
     c->grid_vertices = verts;
     return OCEAN_OK;
 }
@@ -703,8 +800,10 @@ int ocean_displace_grid_cascades(ocean_t* c, uint32_t first_tile, uint32_t count
     a.g.vertex_distance = vertex_distance; a.g.uv_scale = 1.0f; a.g.choppy = choppy;
     a.count = (int)count; a.tile_texels = n2;
     for (uint32_t i = 0; i < (uint32_t)OCEAN_MAX_CASCADES; ++i) a.uv_scale[i] = i < count ? uv_scales[i] : 0.0f;
+    CONSUMER_BEGIN(c, stream_of(c, c->last_set));
     hipLaunchKernelGGL(k_displace_grid_cascades, dim3((verts + 255) / 256), dim3(256), 0, stream_of(c, c->last_set), a);
     HIP_TRY(hipGetLastError());
+    CONSUMER_END(c, stream_of(c, c->last_set));
     c->grid_vertices = verts;
     return OCEAN_OK;
 }
@@ -752,6 +851,7 @@ int ocean_build_mips(ocean_t* c, uint32_t tile)
     m.src[1] = (c->ext_nrm ? c->ext_nrm : c->nrmN[c->last_set]) + tile * n2;
     m.dst[0] = c->mips_disp; m.dst[1] = c->mips_nrm;
     hipStream_t st = stream_of(c, c->last_set);            // ordered after the frame that wrote these maps
+    CONSUMER_BEGIN(c, st);
     for (uint32_t w = n / 2; w >= 1; w /= 2) {
         m.w = (int)w;
         hipLaunchKernelGGL(k_mip_level, dim3((w * w + 255) / 256, 2), dim3(256), 0, st, m);
@@ -759,6 +859,7 @@ int ocean_build_mips(ocean_t* c, uint32_t tile)
         m.dst[0] += (size_t)w * w; m.dst[1] += (size_t)w * w;
     }
     HIP_TRY(hipGetLastError());
+    CONSUMER_END(c, st);
     c->mips_ready = true;
     return OCEAN_OK;
 }
@@ -957,6 +1058,14 @@ int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, siz
     return OCEAN_OK;
 }
 #endif
+
+int ocean_last_launch(const ocean_t* c, int idx, ocean_launch_info* out)
+{
+    if (!c || !out || idx < 0 || idx > 2) return OCEAN_E_INVALID;
+    if (!c->have_frame) return OCEAN_E_NOT_READY;
+    *out = c->last_launch[idx];
+    return OCEAN_OK;
+}
 
 const char* ocean_kernel_name(const ocean_t* c, int idx)
 {

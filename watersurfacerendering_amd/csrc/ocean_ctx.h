@@ -48,10 +48,14 @@ struct ocean_ctx {
     float2* z[MAXD] = {};
     float2* zh[MAXD] = {};
     float* hraw[MAXD] = {};
-    float* jraw[MAXD] = {};        // OCEAN_MODE_JACOBIAN intermediates (allocated with the chain)
+    float2* z3[MAXD] = {};         // OCEAN_MODE_JACOBIAN intermediates: pair 3, cross derivative, product of the diagonal factors --
+    float* jraw[MAXD] = {};        // allocated by a chain's first frame of that mode (alloc_jacobian), never by the others
     float* jac0[MAXD] = {};
     unsigned* minmax[MAXD] = {};
-    unsigned* mm_host[MAXD] = {};   // pinned, device-visible copy of minmax written by the last kernel of a frame
+    uint4* done_rec[MAXD] = {};     // [tiles] host-coherent completion records (min key, max key, sequence, 0) written by the last
+                                    //   workgroup of a frame's last kernel (ocean_kernels.h: frame_done)
+    unsigned* done_ctr[MAXD] = {};  // device counter of that kernel's finished workgroups
+    unsigned seq[MAXD] = {};        // sequence number of the chain's most recently enqueued frame (0: none since the buffers exist)
     float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
     float4* nrmN[MAXD] = {};
     float4* ext_disp = nullptr;
@@ -83,6 +87,10 @@ struct ocean_ctx {
     hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
     hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
     hipEvent_t mark_ev[MAXD][6] = {};   // per-launch timing: (start, stop) of each of the three kernels of a frame
+    ocean_launch_info last_launch[3] = {};  // what the most recent frame launched (ocean_last_launch)
+    hipEvent_t consumer_ev = nullptr;   // behind the most recent consumer launch (mips, grid): the context-wide output buffers of
+    hipStream_t consumer_stream = nullptr;  // those are re-used, so a consumer launch on ANOTHER chain's stream first waits for it
+    bool consumer_pending = false;
     // ---- packed-map gather over RCCL (ocean_comm_init / ocean_gather_maps)
     ncclComm_t comm = nullptr;
     int comm_ranks = 0, comm_rank = -1;

@@ -144,9 +144,11 @@ struct FrameArgs {
     const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
     const float2* tw;        // [N]             exp(+2 pi i k / N)
-    float2* z;               // [tiles][4][NUP/ZB][2][N/2+1][ZB] z-transformed pairs (the 4th only in OCEAN_MODE_JACOBIAN): element (column nb,
+    float2* z;               // [tiles][3][NUP/ZB][2][N/2+1][ZB] z-transformed pairs 0..2: element (column nb,
                              //   side, row q) at Half<N>::zidx -- side 0 = rows q = 0..N/2, side 1 = rows (N-q)%N; NUP = N/2 + 16 rounded
                              //   down to a multiple of 16; ZB = 8 rows per block (16 in the half2 form)
+    float2* z3;              // [tiles][NUP/ZB][2][N/2+1][ZB]   pair 3 = (height, cross derivative), same layout: OCEAN_MODE_JACOBIAN only
+                             //   (allocated with jraw / jac0 by the first frame of that mode, null before)
     float2* zh;              // [tiles][NUP/ZB][N/2+1][ZB]   z-transformed height, rows 0..N/2 (Half<N>::zhidx)
     const float4* zscale;    // [tiles][2] powers of two of the half2 intermediates (Z16 kernels): [0] = (s_u, s_k, 1/s_u, 1/s_k) for the pairs
                              //   weighted by unit vectors / by k; [1] = (s_3, g, 1/s_3, 1/g) for pair 3 of the Jacobian mode, whose
@@ -155,7 +157,10 @@ struct FrameArgs {
     float* jraw;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: signed d(Dx)/dz = d(Dz)/dx of the same rows
     float* jac0;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: (1 + lambda dDx/dx)(1 + lambda dDz/dz) of the same rows
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
-    unsigned* minmax_host;   // [tiles][2]       host-coherent copy, written by the displacement pass
+    uint4* done_rec;         // [tiles]          host-coherent completion records (min key, max key, frame_seq, 0), written by the
+                             //                  displacement pass's last workgroup (frame_done)
+    unsigned* done_ctr;      // [1]              workgroups of the displacement pass that have finished (the last one resets it)
+    unsigned frame_seq;      // sequence number of this frame on its chain (never 0)
     float4* disp;            // [tiles][N][N]
     float4* nrm;             // [tiles][N][N]
     const float* toff;       // [tiles] or null
@@ -400,7 +405,10 @@ __device__ __forceinline__ float height_re(float h0r, float h0i, float c, float 
 // e of column nb TOGETHER with element (N-e)%N of the mirror column (N-nb)%N (S+- = (a +- b)/2).  One sincos therefore serves
 // both: half the sincos and half the dispersion reads of animating the two columns separately, and S+, S-(0) are formed in
 // the registers that hold a and b (no staging of h~ in LDS, one barrier less).  Items are element PAIRS (n, n+1), n even.
-template <int N, bool H16, bool W16>
+// The fp16 copy of the spectrum (ocean_set_spectrum_precision(16)) and the fp32 dispersion array (the fallback when some multiple
+// of the base frequency needs more than 16 bits) are chosen by wave-uniform branches on the launch arguments, not by template
+// flags: neither is worth a kernel instantiation of its own (the fp16 spectrum measured no gain, the fallback is rare).
+template <int N>
 __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
                                                 float4& ha, float2& hb0, float2& hb1, float2& w)
 {
@@ -412,7 +420,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
     ha = make_float4(1.f + g, 2.f, 3.f, 4.f); hb0 = make_float2(0.5f, 1.5f); hb1 = make_float2(2.5f, 3.5f); w = make_float2(0.5f, 0.25f);
     return;
 #endif
-    if constexpr (H16) {
+    if (a.h0h) {
         const __half2* __restrict__ hh = a.h0h + tile * n2;
         const float2 raw2 = *reinterpret_cast<const float2*>(hh + g);       // two half2
         const __half2 x0 = *reinterpret_cast<const __half2*>(&raw2.x), x1 = *reinterpret_cast<const __half2*>(&raw2.y);
@@ -424,7 +432,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
         ha = *reinterpret_cast<const float4*>(h0 + g);
         hb0 = h0[m0]; hb1 = h0[m1];
     }
-    if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
+    if (a.omega_q) {          // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
         const unsigned two = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
         w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
     } else {
@@ -456,7 +464,7 @@ template <int N> struct Half {
     static constexpr int NU = N / 2 + 1;          // columns (units) / rows kept: 0..N/2
     static constexpr int NUP = (N / 2 + 16) & ~15;   // rows 0..N/2 padded to a multiple of 16
     static constexpr size_t Z_GROUP = (size_t)NU * 2 * NUP;       // float2 per packed pair
-    static constexpr size_t Z_TILE = 4 * Z_GROUP;                 // pairs 0..2, and pair 3 = (height, cross derivative) of OCEAN_MODE_JACOBIAN
+    static constexpr size_t Z_TILE = 3 * Z_GROUP;                 // pairs 0..2 (pair 3 = (height, cross derivative) of OCEAN_MODE_JACOBIAN: FrameArgs::z3)
     static constexpr size_t ZH_TILE = (size_t)NU * NUP;
     static constexpr size_t HRAW_TILE = (size_t)NUP * N;          // floats
     // element (column nb, side, row q) of a packed pair's group, and (column nb, row q) of the height's half plane:
@@ -547,6 +555,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     // element offsets; the half2 form packs the same elements at 4 bytes each from the same base address
     constexpr size_t ES = Z16 ? 4 : 8;
     float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + (size_t)tile * HF::Z_TILE * ES);
+    float2* __restrict__ z3 = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z3) + (size_t)tile * HF::Z_GROUP * ES);
     float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
     // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored positions 0 and N/2 exist on side 0
     // only: the x pass knows)
@@ -586,7 +595,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         auto out = [&](int p, int c, c32 v, int, int) {
             const unsigned pos = zpos(p);
             if (c == 3) {
-                if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + pos, v, s3);
+                if (jac) store_z<ZNT, Z16>(z3, pos, v, s3);
                 else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb, p), v, su);
                 return;
             }
@@ -654,7 +663,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + zpos(p), v, s3);
+                if (jac) store_z<ZNT, Z16>(z3, zpos(p), v, s3);
                 else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb, p), v, su);     // real input: other half is the conjugate
                 return;
             }
@@ -669,7 +678,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // Two neighbouring spectrum columns nb0, nb0 + 1 (neither the Nyquist column 0 nor beyond N/2) in one workgroup: four batches
 // of two interleaved transforms, batch g = pair g (g = 3: the height, or pair 3 of the Jacobian mode) of BOTH columns, so that
 // lanes 0-31 / 32-63 of a last-stage store hold the same 32 rows of column nb0 / nb0 + 1: 4 x (64 + 64) contiguous bytes.
-template <int N, int T, class P, bool H16, bool W16, bool ZNT, bool Z16>
+template <int N, int T, class P, bool ZNT, bool Z16>
 __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned char* smem, const TwiddleRegs<N, 2, T, P>& twr,
                                                   int tid, int tile, int nb0)
 {
@@ -681,8 +690,8 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     float* raw = reinterpret_cast<float*>(fbuf);                           // [0], [1]: S-(0) of the two columns, until the first exchange
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
-    const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
-    const float base = W16 ? a.base_freq[tile] : 0.0f;
+    const float h16s = a.h0h ? a.h0_inv_scale[tile] : 1.0f;
+    const float base = a.omega_q ? a.base_freq[tile] : 0.0f;
     {   // phase 1: columns nb0 and nb0 + 1, each with its mirror (zpass_load_pair)
         constexpr int ITEMS = N;                      // 2 columns * N/2 element pairs
         constexpr int P1 = ITEMS / T;
@@ -695,7 +704,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int it = tid + (ub + u) * T;
-                zpass_load_pair<N, H16, W16>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                zpass_load_pair<N>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -719,6 +728,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     if (a.mode == 3) g3 = a.zscale[2 * tile + 1].y;
     constexpr size_t ES = Z16 ? 4 : 8;
     float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + (size_t)tile * HF::Z_TILE * ES);
+    float2* __restrict__ z3 = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z3) + (size_t)tile * HF::Z_GROUP * ES);
     float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
     const float kx0 = k1[nb0], kx1 = k1[nb0 + 1];
     const bool jac = a.mode == 3;
@@ -764,7 +774,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             return zpass_input<3>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, true, g3);
         };
         auto out = [&](int p, int c, c32 v, int, int) {
-            if (jac) store_z<ZNT, Z16>(zt, 3u * (unsigned)HF::Z_GROUP + zpos(p, c), v, s3);
+            if (jac) store_z<ZNT, Z16>(z3, zpos(p, c), v, s3);
             else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb0 + c, p), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
@@ -791,7 +801,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
 // (two columns per workgroup at 2048: 59 KB of LDS allow two workgroups per CU, i.e. four waves per SIMD and 128 VGPRs; the
 //  80-VGPR cap of the one-column form would only make that variant spill)
-template <int N, int T, class P = Plan<N>, bool H16 = false, bool W16 = false, bool ZNT = false, bool Z16 = false, int ZW = 1>
+template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1>
 __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -813,8 +823,8 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;               // [N], cache-resident table
     const bool col0 = (nb == 0);
-    const float h16s = H16 ? a.h0_inv_scale[tile] : 1.0f;
-    const float base = W16 ? a.base_freq[tile] : 0.0f;
+    const float h16s = a.h0h ? a.h0_inv_scale[tile] : 1.0f;
+    const float base = a.omega_q ? a.base_freq[tile] : 0.0f;
 
     OCEAN_STAMP(0);
     // -- phase 1: animate column nb with its mirror nbb (zpass_load_pair); all loads issued before the first sincos.
@@ -833,7 +843,7 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int it = tid + (ub + u) * T;
-                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N, H16, W16>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -869,7 +879,7 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
         constexpr int LAST = N / 4;
         const int blk = (int)blockIdx.x == LAST ? LAST : xcd_swizzle((int)blockIdx.x, LAST);
         if (blk != 0 && blk != LAST) {
-            zpass_two_columns<N, T, P, H16, W16, ZNT, Z16>(a, smem, twr, tid, tile, 2 * blk);
+            zpass_two_columns<N, T, P, ZNT, Z16>(a, smem, twr, tid, tile, 2 * blk);
             return;
         }
         if (blk == LAST) { one_column(N / 2, 3); return; }
@@ -972,12 +982,12 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             constexpr int NW = (T + 63) / 64;
             float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
             const int u0 = xcd_swizzle(blockIdx.x, HB) * C;
-            const float2* __restrict__ z3 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + ((size_t)tile * HF::Z_TILE + 3 * HF::Z_GROUP) * (Z16 ? 4 : 8));
+            const float2* __restrict__ z3 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z3) + (size_t)tile * HF::Z_GROUP * (Z16 ? 4 : 8));
             float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
             float* __restrict__ jraw = a.jraw + (size_t)tile * HF::HRAW_TILE;
             [[maybe_unused]] float ux = 1.0f, uy = 1.0f;
             float ig = 1.0f;                                    // the cross derivative went in amplified by g (zscale): out comes g times it
-            { const float4 z3 = a.zscale[2 * tile + 1]; ig = z3.w; if constexpr (Z16) { ux = z3.z; uy = z3.z; } }
+            { const float4 zs3 = a.zscale[2 * tile + 1]; ig = zs3.w; if constexpr (Z16) { ux = zs3.z; uy = zs3.z; } }
             float vmin = 3.402823466e+38f, vmax = -3.402823466e+38f;
             auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z3, nf, u0 + c, 1.0f, ux, uy); };
             auto out = [&](int p, int c, c32 v, int, int) {
@@ -1134,6 +1144,25 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     }
 }
 
+// Completion record of a frame.  The workgroup of the displacement pass that finishes LAST hands, per tile, one 16-byte record
+// (min key, max key, frame sequence number, 0) to host-coherent memory: a synchronous ComputeWaves returns from a short poll of
+// those words instead of a stream synchronisation (ocean_compute_waves; 13-16 us of wake-up per call at the reference's call
+// shape, WaterSurfaceMesh.cpp:145-154).  A record is one store instruction of one lane -- the host never sees half of one -- and
+// carries its own sequence number, so nothing depends on the order in which records arrive.  It tells the host that the frame's
+// work is done; it is not a memory fence: whatever reads the maps is ordered by the stream, as before.
+template <int T>
+__device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_flag, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's map stores have been taken
+    __syncthreads();                                        // ... every wave's; nobody reads the FFT image any more
+    if (tid == 0) lds_flag[0] = atomicAdd(a.done_ctr, 1u) == gridDim.x * gridDim.y - 1u;
+    __syncthreads();
+    if (!lds_flag[0]) return;
+    if (tid == 0) *a.done_ctr = 0u;                         // for the chain's next frame (stream order)
+    for (unsigned i = (unsigned)tid; i < gridDim.y; i += (unsigned)T)
+        a.done_rec[i] = make_uint4(a.minmax[2 * i + 0], a.minmax[2 * i + 1], a.frame_seq, 0u);     // one 16-byte store
+}
+
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
 {
@@ -1170,11 +1199,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
             }
         }
     }
-    const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];
-    if (blockIdx.x == 0 && tid == 0) {      // final by now: hand the keys to the host (ocean_get_heights, ComputeWaves)
-        a.minmax_host[2 * tile + 0] = kmn;
-        a.minmax_host[2 * tile + 1] = kmx;
-    }
+    const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];      // final by now
     const float mn = key_float(kmn);
     const float mx = key_float(kmx);
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
@@ -1195,11 +1220,11 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
         if (q != 0 && q != N / 2)       // mirror: the displacements are odd, height and Jacobian even
             OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, w));
     };
-    if (a.mode == 2) {               // HEIGHT1: no horizontal displacement, no transform
+    if (a.mode == 2)                 // HEIGHT1: no horizontal displacement, no transform
         for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
-        return;
-    }
-    batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    else
+        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
 }
 
 #ifdef OCEAN_INIT_KERNELS

@@ -44,11 +44,9 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     if (c->attr_n != (uint32_t)N) {
-#define OCEAN_ALLOW_Z(h16, w16, znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, lds_rows)) != hipSuccess) return e; \
-        if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16, 2>, lds_rows2)) != hipSuccess) return e;
-#define OCEAN_ALLOW_Z4(h16, w16) OCEAN_ALLOW_Z(h16, w16, false, false) OCEAN_ALLOW_Z(h16, w16, true, false) OCEAN_ALLOW_Z(h16, w16, false, true) OCEAN_ALLOW_Z(h16, w16, true, true)
-        OCEAN_ALLOW_Z4(false, false) OCEAN_ALLOW_Z4(true, false) OCEAN_ALLOW_Z4(false, true) OCEAN_ALLOW_Z4(true, true)
-#undef OCEAN_ALLOW_Z4
+#define OCEAN_ALLOW_Z(znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16>, lds_rows)) != hipSuccess) return e; \
+        if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2>, lds_rows2)) != hipSuccess) return e;
+        OCEAN_ALLOW_Z(false, false) OCEAN_ALLOW_Z(true, false) OCEAN_ALLOW_Z(false, true) OCEAN_ALLOW_Z(true, true)
 #undef OCEAN_ALLOW_Z
 #define OCEAN_ALLOW_X(kern, lds) \
         if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, false, false, false>, lds)) != hipSuccess) return e; \
@@ -76,38 +74,40 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
     {
         // two neighbouring columns per workgroup (k_zpass<..., 2>): 4096^2 always, from 1024 up when the intermediates are streamed
-        static const char* const zw_env = getenv("OCEAN_ZW");                   // developer override (A/B runs): 1 or 2
         bool zw2 = HAS2 && (N == 4096 || (stream_maps & 4));
+#ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
+        static const char* const zw_env = getenv("OCEAN_ZW");                   // 1 or 2
         if (zw_env && HAS2) zw2 = atoi(zw_env) == 2 && (N == 4096 || (stream_maps & 4));
+#endif
         unsigned gx = zw2 ? N / 4 + 1 : N / 2 + 1;
         FrameArgs za = a;
         za.zfull = (int)gx;
+        bool split = false;
         if ((stream_maps & 16) && tiles == 1 && zpass_columns<N>() == 2 && !zw2) {
             // serial frames: split the columns of the last, partially filled round over two workgroups each
             const unsigned slots = (unsigned)zpass_blocks_per_cu<N, G::T_ROWS>() * (unsigned)c->cu_count;
             const unsigned rest = gx % slots;
-            if (gx > slots && rest != 0 && 2 * rest <= slots) { za.zfull = (int)(gx - rest); gx = (gx - rest) + 2 * rest; }
+            if (gx > slots && rest != 0 && 2 * rest <= slots) { za.zfull = (int)(gx - rest); gx = (gx - rest) + 2 * rest; split = true; }
         }
 #ifdef OCEAN_STAMPS
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
-#define OCEAN_ZPASS2(h16, w16, znt, z16) \
-        do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16, 2>, grid, block, lds_rows2, st, marks, za); break; } } \
-             launch(k_zpass<N, G::T_ROWS, typename G::PR, h16, w16, znt, z16>, grid, block, lds_rows, st, marks, za); } while (0)
-#define OCEAN_ZPASS(h16, w16, znt) \
-        do { if (stream_maps & 8) OCEAN_ZPASS2(h16, w16, znt, true); else OCEAN_ZPASS2(h16, w16, znt, false); } while (0)
-        const int variant = (a.h0h ? 4 : 0) | (a.omega_q ? 2 : 0) | ((stream_maps & 4) ? 1 : 0);
-        switch (variant) {
-            case 0: OCEAN_ZPASS(false, false, false); break;
-            case 1: OCEAN_ZPASS(false, false, true); break;
-            case 2: OCEAN_ZPASS(false, true, false); break;
-            case 3: OCEAN_ZPASS(false, true, true); break;
-            case 4: OCEAN_ZPASS(true, false, false); break;
-            case 5: OCEAN_ZPASS(true, false, true); break;
-            case 6: OCEAN_ZPASS(true, true, false); break;
-            default: OCEAN_ZPASS(true, true, true); break;
+        {
+            ocean_launch_info& li = c->last_launch[0];
+            li.tile_size = N; li.grid_x = gx; li.grid_y = tiles; li.block = G::T_ROWS; li.mode = (uint32_t)a.mode;
+            li.per_workgroup = zw2 ? 2u : 1u;
+            li.lds_bytes = (uint32_t)(zw2 ? lds_rows2 : lds_rows);
+            li.flags = ((stream_maps & 4) ? OCEAN_LAUNCH_NT_INTER : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
+                       (a.mode == 3 ? OCEAN_LAUNCH_JACOBIAN : 0u) | (a.h0h ? OCEAN_LAUNCH_FP16_SPECTRUM : 0u) |
+                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (split ? OCEAN_LAUNCH_SPLIT_LAST_ROUND : 0u);
         }
+#define OCEAN_ZPASS2(znt, z16) \
+        do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2>, grid, block, lds_rows2, st, marks, za); break; } } \
+             launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16>, grid, block, lds_rows, st, marks, za); } while (0)
+#define OCEAN_ZPASS(znt) \
+        do { if (stream_maps & 8) OCEAN_ZPASS2(znt, true); else OCEAN_ZPASS2(znt, false); } while (0)
+        if (stream_maps & 4) OCEAN_ZPASS(true); else OCEAN_ZPASS(false);
 #undef OCEAN_ZPASS
 #undef OCEAN_ZPASS2
     }
@@ -124,6 +124,14 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
         hipEvent_t* mb = marks ? marks + 2 : nullptr;
         hipEvent_t* md = marks ? marks + 4 : nullptr;
+        for (int k = 1; k <= 2; ++k) {
+            ocean_launch_info& li = c->last_launch[k];
+            li.tile_size = N; li.grid_x = k == 1 ? gb.x : gd.x; li.grid_y = tiles; li.block = G::T_C; li.mode = (uint32_t)a.mode;
+            li.per_workgroup = C;
+            li.lds_bytes = (uint32_t)(k == 1 ? lds_b : lds_m);
+            li.flags = ((stream_maps & (k == 1 ? 1 : 2)) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u);
+        }
 #define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16)                                                                \
         do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, a);          \
              else launch(kern<N, C, G::T_C, typename G::PC, nts, z16, false>, grid, blk, lds, st, ev, a); } while (0)
