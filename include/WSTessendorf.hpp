@@ -127,6 +127,7 @@ public:
         if (m_Pending) Wait();
         const int back = m_Front ^ 1;
         const size_t n2 = m_Displacements[m_Front].size();
+        if (!m_Tracking) { Check(ocean_set_frame_tracking(m_Ctx, 1), "ocean_set_frame_tracking"); m_Tracking = true; }
         if (m_Displacements[back].size() != n2) {
             m_Displacements[back].assign(n2, Displacement(0.f, 0.f, 0.f, 0.f));
             m_Normals[back].assign(n2, Normal(0.f, 1.f, 0.f, 0.f));
@@ -228,6 +229,7 @@ private:
     std::vector<Normal> m_Normals[2];
     int m_Front{ 0 };
     bool m_Pending{ false };                          // a ComputeWavesAsync whose copy has not been waited for
+    bool m_Tracking{ false };                         // asynchronous frames leave completion records (ocean_set_frame_tracking)
     float m_PendingMin{ -1.0f }, m_PendingMax{ 1.0f };
     float m_MinHeight{ -1.0f };     // WSTessendorf.h:227-228
     float m_MaxHeight{ 1.0f };

@@ -111,14 +111,20 @@ int ocean_compute_waves(ocean_t* ctx, float t, float* out_amp);
 int ocean_compute_waves_async(ocean_t* ctx, float t);
 /* Waits for the most recently enqueued frame -- not for copies or gathers enqueued behind it -- and writes its height
  * amplitudes to out_amp[tiles] (may be NULL).  ocean_compute_waves = ocean_compute_waves_async + ocean_wait_frame.
- * The wait is a short poll of completion records the frame's last kernel leaves in host-coherent memory (no stream
- * synchronisation, whose wake-up costs 13-16 us per call at the reference's call shape, WaterSurfaceMesh.cpp:145-154);
- * after 2 ms of polling it falls back to hipStreamSynchronize.  When it returns, every workgroup of the frame has finished;
+ * Behind ocean_compute_waves (and behind asynchronous frames after ocean_set_frame_tracking) the wait is a short poll of
+ * completion records the frame's last workgroup leaves in host-coherent memory -- no stream synchronisation, whose wake-up
+ * costs 13-16 us per call at the reference's call shape, WaterSurfaceMesh.cpp:145-154; after 2 ms of polling it falls back
+ * to hipStreamSynchronize.  When it returns, every workgroup of the frame has finished;
  * whatever then reads the maps is ordered by the stream as always (read-out calls, ocean_stream, ocean_synchronize).
  * With ocean_read_maps_async / ocean_read_maps_staging enqueued BEFORE the wait, the caller gets A while the DMA of the
  * maps is still in flight: the reference's DOUBLE_BUFFERED idea (WaterSurfaceMesh.h:26-34) on the synthesis side;
  * include/WSTessendorf.hpp: ComputeWavesAsync() / Wait().                                                                */
 int ocean_wait_frame(ocean_t* ctx, float* out_amp);
+/* Completion records cost the frame's last kernel a count of its finished workgroups (about 1 us at 2048^2, nothing when
+ * frames are pipelined), so only ocean_compute_waves asks for them by default: behind a plain ocean_compute_waves_async,
+ * ocean_wait_frame is a stream synchronisation.  on != 0: asynchronous frames leave them too (what ComputeWavesAsync() of
+ * include/WSTessendorf.hpp switches on).                                                                                 */
+int ocean_set_frame_tracking(ocean_t* ctx, int on);
 int ocean_set_time_offsets(ocean_t* ctx, const float* offsets_or_null /* tiles */);
 int ocean_synchronize(ocean_t* ctx);
 

@@ -39,6 +39,12 @@ def test_wait_frame_returns_this_frames_amplitude_every_time():
         d = np.empty((1, n, n, 4), np.float32); q = np.empty_like(d)
         W.host_register(d); W.host_register(q)
         try:
+            for tracking in (False, True):          # untracked: the wait is a stream synchronisation; tracked: a poll of the records
+                b.set_frame_tracking(tracking)
+                b.compute_waves_async(ts[7 + tracking])
+                b.read_maps_async(d, q)
+                assert float(b.wait_frame()[0]) == want[7 + tracking][0]
+                b.synchronize()
             b.compute_waves_async(ts[7])
             b.read_maps_async(d, q)
             assert float(b.wait_frame()[0]) == want[7][0]
@@ -72,6 +78,7 @@ def test_pipelined_frames_each_have_their_own_completion_records():
     n = 256
     b = W.OceanBatch(n, 3, 0)
     b.set_pipeline_depth(4)
+    b.set_frame_tracking(True)
     b.prepare(SEED)
     r = W.OceanBatch(n, 3, 0)
     r.prepare(SEED)

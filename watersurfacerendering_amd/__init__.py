@@ -110,6 +110,10 @@ class OceanBatch:
         _abi.check(self._L.ocean_wait_frame(self._h, amp.ctypes.data_as(C.POINTER(C.c_float))), "ocean_wait_frame")
         return amp
 
+    def set_frame_tracking(self, on: bool):
+        """Asynchronous frames leave completion records too, so that wait_frame() polls instead of synchronising the stream."""
+        _abi.check(self._L.ocean_set_frame_tracking(self._h, int(bool(on))), "ocean_set_frame_tracking")
+
     def set_time_offsets(self, offsets):
         if offsets is None:
             _abi.check(self._L.ocean_set_time_offsets(self._h, None), "ocean_set_time_offsets")

@@ -32,7 +32,7 @@ SYMBOLS = [
     "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_last_hip_error",
     "ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_set_lambda",
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
-    "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_time_offsets", "ocean_synchronize",
+    "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_frame_tracking", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
     "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_bind_output",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
         "ocean_compute_waves": (i32, [P, f32, FP]),
         "ocean_compute_waves_async": (i32, [P, f32]),
         "ocean_wait_frame": (i32, [P, FP]),
+        "ocean_set_frame_tracking": (i32, [P, i32]),
         "ocean_set_time_offsets": (i32, [P, C.c_void_p]),
         "ocean_synchronize": (i32, [P]),
         "ocean_get_heights": (i32, [P, u32, FP, FP, FP]),

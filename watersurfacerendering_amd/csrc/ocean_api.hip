@@ -71,8 +71,8 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     HIP_TRY(hipMemsetAsync(c->zh[i], 0, t * nu * nup * sizeof(float2), stream_of(c, i)));
     HIP_TRY(hipMemsetAsync(c->hraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
     HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
-    HIP_TRY(hipMalloc(&c->done_ctr[i], sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(c->done_ctr[i], 0, sizeof(unsigned), stream_of(c, i)));
+    HIP_TRY(hipMalloc(&c->done_ctr[i], (1 + DONE_GROUPS) * DONE_STRIDE * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(c->done_ctr[i], 0, (1 + DONE_GROUPS) * DONE_STRIDE * sizeof(unsigned), stream_of(c, i)));
     // the last workgroup of a frame drops (min key, max key, sequence number) per tile into this host-coherent
     // buffer: the synchronous ComputeWaves polls it -- no stream synchronisation, no device-to-host copy
     HIP_TRY(hipHostMalloc((void**)&c->done_rec[i], t * sizeof(uint4), hipHostMallocMapped | hipHostMallocCoherent));
@@ -431,7 +431,7 @@ static const char* kernel_name_of(int idx)
 }
 
 // Enqueues one frame.  pipelined = the call may use the pipeline chains (depth > 1).
-static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks)
+static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks, bool track = false)
 {
     if (!c) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
@@ -465,7 +465,8 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
-    a.done_rec = c->done_rec[set]; a.done_ctr = c->done_ctr[set];
+    a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
+    c->tracked[set] = track;
     if (++c->seq[set] == 0) c->seq[set] = 1;            // never 0: a fresh record buffer reads as "no frame"
     a.frame_seq = c->seq[set];
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
@@ -538,7 +539,14 @@ int ocean_compute_waves_async(ocean_t* c, float t)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    return enqueue_frame(c, t, true, nullptr);
+    return enqueue_frame(c, t, true, nullptr, c->track_async);
+}
+
+int ocean_set_frame_tracking(ocean_t* c, int on)
+{
+    if (!c) return OCEAN_E_INVALID;
+    c->track_async = on != 0;
+    return OCEAN_OK;
 }
 
 int ocean_synchronize(ocean_t* c)
@@ -557,9 +565,14 @@ static int wait_frame(ocean_ctx* c, int set)
     if (!c->have_frame || !c->done_rec[set] || c->seq[set] == 0) return OCEAN_E_NOT_READY;
     const unsigned want = c->seq[set];
     const volatile uint4* rec = c->done_rec[set];
+    bool synced = false;
+    if (!c->tracked[set]) {           // the records arrive early in the frame's last kernel: only the stream tells when it has finished
+        HIP_TRY(hipStreamSynchronize(stream_of(c, set)));
+        synced = true;
+    }
     using clock = std::chrono::steady_clock;
     clock::time_point t0;
-    bool timed = false, synced = false;
+    bool timed = false;
     unsigned spins = 0;
     for (uint32_t i = 0; i < c->tiles; ++i) {
         while (__atomic_load_n(&rec[i].z, __ATOMIC_ACQUIRE) != want) {
@@ -602,7 +615,7 @@ int ocean_compute_waves(ocean_t* c, float t, float* out_amp)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = enqueue_frame(c, t, true, nullptr);
+    int rc = enqueue_frame(c, t, true, nullptr, true);
     if (rc) return rc;
     return ocean_wait_frame(c, out_amp);        // waits for this frame only
 }

@@ -54,7 +54,10 @@ struct ocean_ctx {
     unsigned* minmax[MAXD] = {};
     uint4* done_rec[MAXD] = {};     // [tiles] host-coherent completion records (min key, max key, sequence, 0) written by the last
                                     //   workgroup of a frame's last kernel (ocean_kernels.h: frame_done)
-    unsigned* done_ctr[MAXD] = {};  // device counter of that kernel's finished workgroups
+    unsigned* done_ctr[MAXD] = {};  // device counters of that kernel's finished workgroups (two levels: ocean_kernels.h, frame_done)
+    bool tracked[MAXD] = {};        // the chain's most recent frame counts its finished workgroups (completion records written LAST:
+                                    //   ocean_wait_frame polls); otherwise the records only carry the height keys and the wait is a stream synchronisation
+    bool track_async = false;       // ocean_set_frame_tracking: asynchronous frames are tracked too (the synchronous call always is)
     unsigned seq[MAXD] = {};        // sequence number of the chain's most recently enqueued frame (0: none since the buffers exist)
     float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
     float4* nrmN[MAXD] = {};

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 #include "fft_engine.h"
 
 // Diagnostic builds (never shipped; `make -C csrc variant NAME=x DEFS=...`): -DOCEAN_STAMPS records
@@ -405,10 +406,24 @@ __device__ __forceinline__ float height_re(float h0r, float h0i, float c, float 
 // e of column nb TOGETHER with element (N-e)%N of the mirror column (N-nb)%N (S+- = (a +- b)/2).  One sincos therefore serves
 // both: half the sincos and half the dispersion reads of animating the two columns separately, and S+, S-(0) are formed in
 // the registers that hold a and b (no staging of h~ in LDS, one barrier less).  Items are element PAIRS (n, n+1), n even.
-// The fp16 copy of the spectrum (ocean_set_spectrum_precision(16)) and the fp32 dispersion array (the fallback when some multiple
-// of the base frequency needs more than 16 bits) are chosen by wave-uniform branches on the launch arguments, not by template
-// flags: neither is worth a kernel instantiation of its own (the fp16 spectrum measured no gain, the fallback is rare).
-template <int N>
+// H16: the fp16 copy of the spectrum (ocean_set_spectrum_precision(16)); W16: the dispersion as 16-bit multiples of the base
+// frequency (false: the fp32 array, the fallback when some multiple needs more bits).  Neither is worth a kernel instantiation
+// of its own -- the fp16 spectrum measured no gain, the fallback is rare -- so one kernel holds the four forms of its phase 1
+// and picks one by a wave-uniform branch on the launch arguments (spectrum_form); the branch sits OUTSIDE the load loop: with
+// it inside zpass_load_pair the loads of a thread's items no longer all issued ahead of the first sincos (z pass +7 %).  The
+// usual form (fp32 spectrum, 16-bit dispersion) keeps an instantiation without the other three (FAST): carrying them cost the
+// 2048^2 z pass 3 % (26.1 -> 27.0 us) although they never run.
+template <bool FAST, class F>
+__device__ __forceinline__ void spectrum_form(const FrameArgs& a, F&& f)
+{
+    if constexpr (FAST) { f(std::false_type{}, std::true_type{}); return; }     // fp32 spectrum, 16-bit dispersion: the usual form, no branch at all
+    if (__builtin_expect(a.h0h != nullptr, 0)) {
+        if (a.omega_q) f(std::true_type{}, std::true_type{});
+        else f(std::true_type{}, std::false_type{});
+    } else if (__builtin_expect(a.omega_q != nullptr, 1)) f(std::false_type{}, std::true_type{});
+    else f(std::false_type{}, std::false_type{});
+}
+template <int N, bool H16, bool W16>
 __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
                                                 float4& ha, float2& hb0, float2& hb1, float2& w)
 {
@@ -420,7 +435,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
     ha = make_float4(1.f + g, 2.f, 3.f, 4.f); hb0 = make_float2(0.5f, 1.5f); hb1 = make_float2(2.5f, 3.5f); w = make_float2(0.5f, 0.25f);
     return;
 #endif
-    if (a.h0h) {
+    if constexpr (H16) {
         const __half2* __restrict__ hh = a.h0h + tile * n2;
         const float2 raw2 = *reinterpret_cast<const float2*>(hh + g);       // two half2
         const __half2 x0 = *reinterpret_cast<const __half2*>(&raw2.x), x1 = *reinterpret_cast<const __half2*>(&raw2.y);
@@ -432,7 +447,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
         ha = *reinterpret_cast<const float4*>(h0 + g);
         hb0 = h0[m0]; hb1 = h0[m1];
     }
-    if (a.omega_q) {          // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
+    if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
         const unsigned two = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
         w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
     } else {
@@ -678,7 +693,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // Two neighbouring spectrum columns nb0, nb0 + 1 (neither the Nyquist column 0 nor beyond N/2) in one workgroup: four batches
 // of two interleaved transforms, batch g = pair g (g = 3: the height, or pair 3 of the Jacobian mode) of BOTH columns, so that
 // lanes 0-31 / 32-63 of a last-stage store hold the same 32 rows of column nb0 / nb0 + 1: 4 x (64 + 64) contiguous bytes.
-template <int N, int T, class P, bool ZNT, bool Z16>
+template <int N, int T, class P, bool ZNT, bool Z16, bool FAST>
 __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned char* smem, const TwiddleRegs<N, 2, T, P>& twr,
                                                   int tid, int tile, int nb0)
 {
@@ -692,7 +707,8 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
     const float h16s = a.h0h ? a.h0_inv_scale[tile] : 1.0f;
     const float base = a.omega_q ? a.base_freq[tile] : 0.0f;
-    {   // phase 1: columns nb0 and nb0 + 1, each with its mirror (zpass_load_pair)
+    spectrum_form<FAST>(a, [&](auto h16, auto w16) {   // phase 1: columns nb0 and nb0 + 1, each with its mirror (zpass_load_pair)
+        constexpr bool H16 = decltype(h16)::value, W16 = decltype(w16)::value;
         constexpr int ITEMS = N;                      // 2 columns * N/2 element pairs
         constexpr int P1 = ITEMS / T;
         constexpr int PB = P1 > 2 ? 2 : P1;           // items in flight per thread (ten registers each; four spill under 2048's cap)
@@ -704,7 +720,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int it = tid + (ub + u) * T;
-                zpass_load_pair<N>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                zpass_load_pair<N, H16, W16>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -718,7 +734,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 if (n == 0) raw[c] = 0.5f * (a0 - b0);
             }
         }
-    }
+    });
     __syncthreads();
     const float sm00 = raw[0], sm01 = raw[1];      // S-(0) of the two columns
 
@@ -801,7 +817,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
 // (two columns per workgroup at 2048: 59 KB of LDS allow two workgroups per CU, i.e. four waves per SIMD and 128 VGPRs; the
 //  80-VGPR cap of the one-column form would only make that variant spill)
-template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1>
+template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true>
 __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_waves<N>()) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -831,7 +847,8 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
     // S- is needed along the whole column only for the Nyquist column nb == 0 (Tx = S-); every other column needs just
     // S-(0) (Tz at e == 0) and keeps the kz table in LDS instead.  The Nyquist column pairs with itself (nbb == 0): S+ is
     // even and S- odd along e, so ONE array G(e) = h~(e, 0) carries both; every other column stores S+ directly.
-    {
+    spectrum_form<FAST>(a, [&](auto h16, auto w16) {
+        constexpr bool H16 = decltype(h16)::value, W16 = decltype(w16)::value;
         constexpr int PAIRS = N / 2;
         constexpr int P1 = (PAIRS + T - 1) / T;
         constexpr int PB = P1 > 4 ? 4 : P1;          // items in flight per thread
@@ -843,7 +860,7 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int it = tid + (ub + u) * T;
-                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N, H16, W16>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -859,7 +876,7 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
                 }
             }
         }
-    }
+    });
     if (blockIdx.x == 0 && tid == 0) {
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
         a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
@@ -879,7 +896,7 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
         constexpr int LAST = N / 4;
         const int blk = (int)blockIdx.x == LAST ? LAST : xcd_swizzle((int)blockIdx.x, LAST);
         if (blk != 0 && blk != LAST) {
-            zpass_two_columns<N, T, P, ZNT, Z16>(a, smem, twr, tid, tile, 2 * blk);
+            zpass_two_columns<N, T, P, ZNT, Z16, FAST>(a, smem, twr, tid, tile, 2 * blk);
             return;
         }
         if (blk == LAST) { one_column(N / 2, 3); return; }
@@ -1150,12 +1167,27 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 // shape, WaterSurfaceMesh.cpp:145-154).  A record is one store instruction of one lane -- the host never sees half of one -- and
 // carries its own sequence number, so nothing depends on the order in which records arrive.  It tells the host that the frame's
 // work is done; it is not a memory fence: whatever reads the maps is ordered by the stream, as before.
+// Counting is two-level -- workgroup -> one of up to DONE_GROUPS group counters (a cache line each) -> the top counter -- because
+// the workgroups of a round finish together and a single word takes ~88 atomics per microsecond (257 of them: +2 us on the 2048^2
+// displacement pass; two-level: see DESIGN.md section 6).
+constexpr unsigned DONE_GROUPS = 1024, DONE_STRIDE = 16;      // counter g at done_ctr[(1 + g) * DONE_STRIDE], the top one at [0]
 template <int T>
 __device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_flag, int tid)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's map stores have been taken
     __syncthreads();                                        // ... every wave's; nobody reads the FFT image any more
-    if (tid == 0) lds_flag[0] = atomicAdd(a.done_ctr, 1u) == gridDim.x * gridDim.y - 1u;
+    if (tid == 0) {
+        const unsigned total = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned groups = total / 16u < DONE_GROUPS ? (total + 15u) / 16u : DONE_GROUPS;
+        const unsigned g = id % groups, members = total / groups + (g < total % groups ? 1u : 0u);
+        unsigned* gc = a.done_ctr + (1u + g) * DONE_STRIDE;
+        bool last = false;
+        if (atomicAdd(gc, 1u) == members - 1u) {             // last of its group: the group counter is free again, one add upstairs
+            *gc = 0u;
+            last = atomicAdd(a.done_ctr, 1u) == groups - 1u;
+        }
+        lds_flag[0] = last;
+    }
     __syncthreads();
     if (!lds_flag[0]) return;
     if (tid == 0) *a.done_ctr = 0u;                         // for the chain's next frame (stream order)
@@ -1200,6 +1232,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
         }
     }
     const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];      // final by now
+    if (!a.done_ctr && blockIdx.x == 0 && tid == 0) a.done_rec[tile] = make_uint4(kmn, kmx, a.frame_seq, 0u);
     const float mn = key_float(kmn);
     const float mx = key_float(kmx);
     const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
@@ -1224,7 +1257,7 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
         for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
     else
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
-    frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
+    if (a.done_ctr) frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
 }
 
 #ifdef OCEAN_INIT_KERNELS

@@ -44,9 +44,11 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     if (c->attr_n != (uint32_t)N) {
-#define OCEAN_ALLOW_Z(znt, z16) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16>, lds_rows)) != hipSuccess) return e; \
-        if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2>, lds_rows2)) != hipSuccess) return e;
-        OCEAN_ALLOW_Z(false, false) OCEAN_ALLOW_Z(true, false) OCEAN_ALLOW_Z(false, true) OCEAN_ALLOW_Z(true, true)
+#define OCEAN_ALLOW_Z(znt, z16, fast) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, lds_rows)) != hipSuccess) return e; \
+        if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, lds_rows2)) != hipSuccess) return e;
+#define OCEAN_ALLOW_Z2(fast) OCEAN_ALLOW_Z(false, false, fast) OCEAN_ALLOW_Z(true, false, fast) OCEAN_ALLOW_Z(false, true, fast) OCEAN_ALLOW_Z(true, true, fast)
+        OCEAN_ALLOW_Z2(true) OCEAN_ALLOW_Z2(false)
+#undef OCEAN_ALLOW_Z2
 #undef OCEAN_ALLOW_Z
 #define OCEAN_ALLOW_X(kern, lds) \
         if ((e = allow_lds(kern<N, C, G::T_C, typename G::PC, false, false, false>, lds)) != hipSuccess) return e; \
@@ -102,14 +104,19 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
                        (a.mode == 3 ? OCEAN_LAUNCH_JACOBIAN : 0u) | (a.h0h ? OCEAN_LAUNCH_FP16_SPECTRUM : 0u) |
                        (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (split ? OCEAN_LAUNCH_SPLIT_LAST_ROUND : 0u);
         }
+        // the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the other forms' code (FAST)
+        const bool fast = !a.h0h && a.omega_q;
+#define OCEAN_ZPASS3(znt, z16, fast) \
+        do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds_rows2, st, marks, za); break; } } \
+             launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds_rows, st, marks, za); } while (0)
 #define OCEAN_ZPASS2(znt, z16) \
-        do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2>, grid, block, lds_rows2, st, marks, za); break; } } \
-             launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16>, grid, block, lds_rows, st, marks, za); } while (0)
+        do { if (fast) OCEAN_ZPASS3(znt, z16, true); else OCEAN_ZPASS3(znt, z16, false); } while (0)
 #define OCEAN_ZPASS(znt) \
         do { if (stream_maps & 8) OCEAN_ZPASS2(znt, true); else OCEAN_ZPASS2(znt, false); } while (0)
         if (stream_maps & 4) OCEAN_ZPASS(true); else OCEAN_ZPASS(false);
 #undef OCEAN_ZPASS
 #undef OCEAN_ZPASS2
+#undef OCEAN_ZPASS3
     }
 #ifdef OCEAN_STAMPS
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
