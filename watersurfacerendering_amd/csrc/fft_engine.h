@@ -229,6 +229,13 @@ template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() *
 
 template <int C>
 __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
+// lds_index(idx0 + d, c) - lds_index(idx0, c) for the element distances d the stages use -- a compile-time constant, so that the
+// R accesses of a butterfly share ONE address register and differ in the instruction's immediate offset (three to four VALU
+// instructions less per LDS access: about 40 % of a middle stage's vector instructions were address arithmetic).  Exact for every
+// access of a Stockham stage with power-of-two radices: reads touch j + i * (N / R) with j < N / R, writes j0 + i * NS with
+// j0 = (j - k) * R + k, k = j % NS < NS; in both cases (idx0 mod 16) + (d mod 16) < 16, so the padding term idx / 16 splits into
+// idx0 / 16 + d / 16 (checked exhaustively for every plan of this file: tools/check_lds_offsets.py).
+template <int C> constexpr int lds_delta(int d) { return (d + d / 16) * C; }
 
 // Work-item -> (column c, butterfly j) of the LAST stage.  Two lane layouts for a batch whose
 // items fill whole waves:
@@ -315,10 +322,11 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
                 int c, j;
                 last_stage_map<N, C, R, LM>(w, c, j);
                 v2 x[R];
+                [[maybe_unused]] const int rb = lds_index<C>(j, c);
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     if constexpr (FIRST) x[i] = tov(in(j + i * (N / R), c, u, i));
-                    else x[i] = ldsv[lds_index<C>(j + i * (N / R), c)];
+                    else x[i] = ldsv[rb + lds_delta<C>(i * (N / R))];
                 }
 #ifndef OCEAN_ABL_NOFFT
                 if constexpr (NS > 1) apply_twiddles<R>(x, tov(twr.w[STAGE][u]));
@@ -340,10 +348,11 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
         const int w = tid + u * T;
         if (!GUARD || w < ITEMS) {
             const int c = w % C, j = w / C;
+            [[maybe_unused]] const int rb = lds_index<C>(j, c);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if constexpr (FIRST) x[u][i] = tov(in(j + i * (N / R), c, u, i));
-                else x[u][i] = ldsv[lds_index<C>(j + i * (N / R), c)];
+                else x[u][i] = ldsv[rb + lds_delta<C>(i * (N / R))];
             }
 #ifndef OCEAN_ABL_NOFFT
             if constexpr (NS > 1) apply_twiddles<R>(x[u], tov(twr.w[STAGE][u]));
@@ -361,8 +370,9 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             const int c = w % C, j = w / C;
             const int k = j % NS;
             const int j0 = (j - k) * R + k;
+            const int wb = lds_index<C>(j0, c);
 #pragma unroll
-            for (int i = 0; i < R; ++i) ldsv[lds_index<C>(j0 + i * NS, c)] = x[u][i];
+            for (int i = 0; i < R; ++i) ldsv[wb + lds_delta<C>(i * NS)] = x[u][i];
         }
     }
 }

@@ -515,6 +515,68 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
 }
 
+// Where a thread's last-stage outputs of a z-axis transform go in the row-blocked intermediates (Half<N>::zidx / zhidx).  The last
+// stage hands work item u, leg i the position p = j + i * S (S = N / last radix, j < S, (u, i) unrolled constants): the side is
+// known per leg at compile time (but for the self-mirrored row N/2) and the index is one of three per-item bases -- computed once
+// per column -- plus a compile-time constant.  The straightforward form (compare p with N/2, divide and modulo by the block
+// height, per output, under divergent branches) was 45 % of the z pass's vector instructions per batch.
+template <int N, int T, class P, int ZC, bool Z16> struct ZStore {
+    using HF = Half<N>;
+    using LS = LastStage<N, ZC, T, P>;
+    static constexpr int S = LS::STRIDE, NU = HF::NU;
+    static constexpr int ZB = HF::template zb<Z16>(), ZBH = ZB > 8 ? ZB : 8;
+    // (not for the half2 four-transform form -- 256^2 and 512^2 with ocean_set_intermediate_precision(16): there the compiler
+    //  leaves the kernel's argument block and a closure in scratch memory with this path, 344 bytes of stack)
+    static constexpr bool FAST = OCEAN_ZTILE != 0 && S >= ZBH && S % ZBH == 0 && (N / 2) % S == 0 && !(Z16 && ZC == 4);
+    int b0[LS::IT], b1[LS::IT], bh[LS::IT];
+    // A base is read through an empty asm: otherwise a choice between two outputs' positions (c ? height : pair 2, ...) is folded
+    // into ONE load with a selected address, which pins the three small arrays in scratch memory instead of registers.
+    static __device__ __forceinline__ int reg(int v) { asm("" : "+v"(v)); return v; }
+    // nb: the column of this workgroup; two_columns: item u's column is nb + c (the two-column z pass)
+    __device__ __forceinline__ void init(int tid, int nb, bool two_columns = false)
+    {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int u = 0; u < LS::IT; ++u) {
+                const int w = tid + u * T;
+                int c = 0, j = 0;
+                if (!LS::GUARD || w < LS::ITEMS) LS::map(w, c, j);
+                const int col = nb + (two_columns ? c : 0);
+                b0[u] = (j / ZB) * (2 * NU * ZB) + (j % ZB) + col * ZB;                           // side 0, row j
+                const int cj = (j + ZB - 1) / ZB, rj = (ZB - j % ZB) % ZB;
+                b1[u] = NU * ZB + col * ZB + rj - cj * (2 * NU * ZB);                              // side 1, row -j (+ a multiple of S)
+                bh[u] = (j / ZBH) * (NU * ZBH) + (j % ZBH) + col * ZBH;                            // height half plane, row j
+            }
+        }
+    }
+    // element of a packed pair's group for output position p (any p)
+    __device__ __forceinline__ unsigned pos(int col, int p, int u, int i) const
+    {
+        if constexpr (!FAST) return p <= N / 2 ? HF::template zidx<Z16>(col, 0, p) : HF::template zidx<Z16>(col, 1, N - p);
+        else {
+            const int lo = i * S;
+            if (lo < N / 2) return (unsigned)(reg(b0[u]) + (lo / ZB) * (2 * NU * ZB));
+            const int far = reg(b1[u]) + ((N - lo) / ZB) * (2 * NU * ZB);
+            if (lo > N / 2) return (unsigned)far;
+            // p == N/2 <=> j == 0: the self-mirrored row lives on side 0, one side's worth (NU * ZB) before what the formula of side 1
+            // gives for j == 0 (written as a correction of `far`, not as a choice between b0 and b1: the latter turns into a load
+            // with a selected address and keeps the bases in scratch memory)
+            return (unsigned)(far - (p == N / 2 ? NU * ZB : 0));
+        }
+    }
+    // the height's half plane keeps rows 0 .. N/2 only
+    __device__ __forceinline__ bool keeps(int p, int i) const
+    {
+        if constexpr (!FAST) return p <= N / 2;
+        else return i * S < N / 2 || (i * S == N / 2 && p == N / 2);
+    }
+    __device__ __forceinline__ unsigned hpos(int col, int p, int u, int i) const
+    {
+        if constexpr (!FAST) return HF::template zhidx<Z16>(col, p);
+        else return (unsigned)(reg(bh[u]) + ((i * S) / ZBH) * (NU * ZBH));      // (row N/2: j == 0, so bh[u] is the column's offset alone)
+    }
+};
+
 // The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
 // column nb == 0, the only one where Tx = S- along the whole column.
 // Interleaved transforms per z-pass batch: 2 (two batches: {pair 0, pair 1}, {pair 2, height}) or 4 (all of a
@@ -574,7 +636,8 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
     float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
     // side 0 holds p = 0..N/2, side 1 holds N-p for p > N/2 (the self-mirrored positions 0 and N/2 exist on side 0
     // only: the x pass knows)
-    auto zpos = [&](int p) -> unsigned { return p <= N / 2 ? HF::template zidx<Z16>(nb, 0, p) : HF::template zidx<Z16>(nb, 1, N - p); };
+    ZStore<N, T, P, ZC, Z16> zo;
+    zo.init(tid, nb);
     // S+(e) and Tx(e), Tz(e)
     auto fetch = [&](int e, float& sv, float& tx, float& tz) {
         if constexpr (COL0) {
@@ -607,11 +670,11 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             const float tc = COL0 ? (e == 0 ? sv : tx) : tz;       // cross derivative: see the two-batch form below
             return c == 2 ? make_float2(kx2 * g, kz * kz * g) : make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
         };
-        auto out = [&](int p, int c, c32 v, int, int) {
-            const unsigned pos = zpos(p);
+        auto out = [&](int p, int c, c32 v, int u, int i) {
+            const unsigned pos = zo.pos(nb, p, u, i);
             if (c == 3) {
                 if (jac) store_z<ZNT, Z16>(z3, pos, v, s3);
-                else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb, p), v, su);
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);
                 return;
             }
             if (a.mode == 2) return;
@@ -637,11 +700,11 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             const float f = c ? -1.0f : inv;                       // pair 1: (-kz Tz, kx Tx); pair 0: (uz Tz, -ux Tx)
             return make_float2(kz * f * tz, -kx * f * tx);
         };
-        auto out = [&](int p, int c, c32 v, int, int) {
+        auto out = [&](int p, int c, c32 v, int u, int i) {
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
-            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zpos(p), v, c ? sk : su);
+            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -673,16 +736,16 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             const float g = full7 * inv * sv;                      // pair 2 only exists in the 7-field modes
             return make_float2(c ? sv : kx2 * g, c ? (jac ? g3 * (kx * kz * inv * tc) : 0.0f) : kz2 * g);
         };
-        auto out = [&](int p, int c, c32 v, int, int) {
+        auto out = [&](int p, int c, c32 v, int u, int i) {
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16>(z3, zpos(p), v, s3);
-                else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb, p), v, su);     // real input: other half is the conjugate
+                if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
                 return;
             }
-            store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zpos(p), v, sk);
+            store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -748,7 +811,8 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
     const float kx0 = k1[nb0], kx1 = k1[nb0 + 1];
     const bool jac = a.mode == 3;
-    auto zpos = [&](int p, int c) -> unsigned { return p <= N / 2 ? HF::template zidx<Z16>(nb0 + c, 0, p) : HF::template zidx<Z16>(nb0 + c, 1, N - p); };
+    ZStore<N, T, P, 2, Z16> zo;
+    zo.init(tid, nb0, true);
     // S+(e), Tz(e) (Tx = S+ off the Nyquist column), kx of column c
     const float kx20 = kx0 * kx0, kx21 = kx1 * kx1;
     auto fetch = [&](int e, int c, float& sv, float& tz, float& kx, float& kx2) {
@@ -763,7 +827,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<0>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int c, c32 v, int, int) { store_z<ZNT, Z16>(zt, zpos(p, c), v, su); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
         {   // pair 1: (-kz Tz, kx Tx)
@@ -771,7 +835,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<1>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int c, c32 v, int, int) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zpos(p, c), v, sk); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
     }
@@ -780,7 +844,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
             return zpass_input<2>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
         };
-        auto out = [&](int p, int c, c32 v, int, int) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zpos(p, c), v, sk); };
+        auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
     {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
@@ -789,9 +853,9 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             if (!jac) return make_float2(sv, 0.0f);
             return zpass_input<3>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, true, g3);
         };
-        auto out = [&](int p, int c, c32 v, int, int) {
-            if (jac) store_z<ZNT, Z16>(z3, zpos(p, c), v, s3);
-            else if (p <= N / 2) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(nb0 + c, p), v, su);     // real input: other half is the conjugate
+        auto out = [&](int p, int c, c32 v, int u, int i) {
+            if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb0 + c, p, u, i), v, s3);
+            else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb0 + c, p, u, i), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
