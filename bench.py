@@ -32,7 +32,15 @@ gather of the packed maps (ocean_gather_maps: ncclGather from the library's own 
 measured after the timed region on BASELINE config 5's share (8 tiles of 1024^2 per rank) and
 reported under "gather": compute only, compute + gather serial, gather overlapped.
 
-Rank 0 prints ONE JSON line.
+BASELINE config 5 (64 independent 1024 x 1024 tiles, 8 per GPU on 8 GPUs) as the timed workload itself:
+
+    python bench.py --gpus 8 --size 1024 --tiles 8 --depth 2
+
+(`config.workload` then reads "64 x 1024x1024 tiles, 8 per GPU"); the default invocation keeps BASELINE's single-GPU
+headline tile (2048 x 2048) per rank and measures config 5's share in the `gather` object.
+
+Rank 0 prints ONE JSON line.  Exit status: 0 only when the line carries every measurement that was asked for; a gather
+that hangs or fails at N > 1 still gets its line out (the timed region is complete by then) but the process exits 3.
 """
 from __future__ import annotations
 
@@ -51,7 +59,8 @@ SEED = 0x5EED0000
 DT = 0.05
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 # Bytes per texel each launch of THIS pipeline has to move: half-size
-# intermediates, 16-bit dispersion.  roofline.achieved / frac use these.
+# intermediates, 16-bit dispersion.  roofline.achieved / frac use the library's own accounting of the measured context
+# (ocean_algorithmic_bytes_per_launch); these are its values for the fp32 seven-field frame, kept for the CPU-side checks.
 KERNEL_BYTES_ACTUAL = {"k_zpass": 23, "k_xpass_b": 28, "k_xpass_disp": 22}
 FRAME_BYTES_ACTUAL = 73.0
 # SURVEY.md 8d's MODEL of a plain two-pass scheme with 3.5 full-size complex intermediates (no point
@@ -298,6 +307,18 @@ def measure_consumer(W, n, device, calls=200):
             "what": "ocean_displace_grid back to back on one stream: bilinear REPEAT sampling of both maps, positions + normals out"}
 
 
+def kernel_source_sha16() -> str:
+    """Hash of the kernel sources: the committed profile summaries carry the hash they were measured with, and their
+    figures are quoted in the line only while it matches (no silently stale numbers beside live ones)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "watersurfacerendering_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_profiles_json(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -305,16 +326,23 @@ def load_profiles_json(name):
         return {}
 
 
-def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, serial_us_per_step, own_bytes_per_texel):
+def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, serial_us_per_step, own_bytes_per_texel,
+                    kernel_bytes=None):
     """Roofline of the dominant (longest) kernel on this pipeline's own bytes, every kernel beside it."""
     traffic = load_profiles_json("traffic.json")
     stats = load_profiles_json("kernel_stats.json")
+    # committed PMC / rocprofv3 summaries are quoted only while they belong to the kernels being measured
+    src = kernel_source_sha16()
+    profiles_current = traffic.get("_kernel_source_sha16") == src and stats.get("_kernel_source_sha16") == src
+    if not profiles_current:
+        traffic, stats = {}, {}
+    kernel_bytes = dict(KERNEL_BYTES_ACTUAL) if kernel_bytes is None else dict(kernel_bytes)
     texels = n * n * tiles
     key = lambda k: f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
     kernels = {}
     for k, ms in zip(names, kern_ms):
         us = ms * 1e3
-        own = KERNEL_BYTES_ACTUAL.get(k, 0) * texels
+        own = kernel_bytes.get(k, 0) * texels
         ent = {"launch_us": us, "own_bytes_per_launch": own, "achieved_GBps": own / (us * 1e-6) * 1e-9}
         ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBPS
         tr = traffic.get(key(k))
@@ -335,14 +363,20 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
         "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["frac"],
         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
         "traffic_source": tr.get("source") if tr else None,
+        "committed_profiles": {"kernel_source_sha16": src, "current": profiles_current,
+                               "note": "traffic / rocprof_launch_us come from profiles/traffic.json and profiles/kernel_stats.json (rocprofv3 runs "
+                                       "of these kernels on another box, tools/prof_round.sh); they are quoted only while the hash of the kernel "
+                                       "sources they were measured with equals the one being run, otherwise null"},
+        "kernel_bytes_per_texel": kernel_bytes,
         "algorithmic_bytes_per_launch": d["own_bytes_per_launch"],
-        "bytes_model": "this pipeline's own algorithmic bytes per texel: k_zpass 23 (h0 8 + 16-bit dispersion of HALF the columns 1 in -- a column "
+        "bytes_model": "this pipeline's own algorithmic bytes per texel (ocean_algorithmic_bytes_per_launch; fp32 seven-field frame:) k_zpass 23 (h0 8 + 16-bit dispersion of HALF the columns 1 in -- a column "
                        "and its point mirror share it --, half-size "
                        "intermediates 14 out), k_xpass_b 28 (10 in, raw height 2 + normal map 16 out), k_xpass_disp 22 (6 in, "
                        "displacement map 16 out); 73 per frame (DESIGN.md section 5)",
         "launch_us": d["launch_us"],
         "launch_us_source": "hipExtLaunchKernelGGL start/stop events on the launch stream (kernel execution time), serial frames, "
-                            "mean over the timed frames; rocprofv3 --kernel-trace --stats of the same command: profiles/kernel_stats.json",
+                            "mean over 200 frames of a pass of its own (independent of --steps / --warmup); rocprofv3 --kernel-trace "
+                            "--stats of the same command: profiles/kernel_stats.json",
         "rocprof_launch_us": d.get("rocprof_launch_us"),
         "regime": "serial frames (pipeline depth 1): every kernel has the GPU to itself",
         "kernels": kernels,
@@ -364,6 +398,37 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
     }
 
 
+def build_line(args, world, n, tiles, frames_per_s, ms_per_step, roofline, gather_obj, extra_obj, cpu, cpu_strong):
+    """The ONE JSON line (a dict) of a run: the contract's keys + roofline + cpu_baseline + gather + extra."""
+    return {
+        "metric": "ocean frames/s (ComputeWaves, 7 fields -> displacement + normal map)",
+        "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "prewarm_frames": args.prewarm, "warmup_frames_effective": args.prewarm + args.warmup,
+        "warmup_note": "`warmup` is the W of the command line; `prewarm_frames` more untimed frames run ahead of them (the device needs a "
+                       "few hundred frames to reach its steady state) -- warmup_frames_effective untimed frames in all; the roofline's per-kernel "
+                       "passes are separate runs of 200 frames each, independent of --steps / --warmup",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"{tiles * world} x {n}x{n} tiles, {tiles} per GPU" if tiles * world > 1 else f"{n}x{n} tile") +
+                               ", FULL7 (7 real fields via 3.5 complex 2-D iFFTs), "
+                               f"{tiles} tile(s) per rank per step, reference default parameters" +
+                               (" = BASELINE config 5" if (n, tiles * world, world) == (1024, 64, 8) else ""),
+                   "tile_size": n, "tiles_per_rank": tiles, "seed": SEED, "dt": DT,
+                   "pipeline_depth": args.depth,
+                   "api": "ocean_compute_waves_async x steps, then ocean_synchronize (frames alternate between "
+                          f"{args.depth} independent chains, each with its own intermediates and map set)",
+                   "parallelism": f"tiles sharded 1 process per GPU x{world}, no data-path collective"},
+        "gtexels_per_s": n * n * frames_per_s * 1e-9,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "cpu_baseline_strong": cpu_strong,
+        "speedup_vs_cpu_baseline_strong": (frames_per_s / cpu_strong["value"]) if cpu_strong and cpu_strong.get("value") else None,
+        "gather": gather_obj,
+        "extra": extra_obj,
+    }
+
+
+
 def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend, red_dev, barrier):
     """SURVEY.md 8e's three figures on BASELINE config 5's per-GPU share (8 tiles of 1024^2 per rank): compute
     only, every batch followed by its gather, and the gather overlapped with the next batch (two map sets).  The
@@ -374,6 +439,7 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
     b.prepare(SEED + first_tile)
     uid = wdist.exchange_unique_id(W, src=0)
     b.comm_init(world, rank, uid)
+    rccl_ranks, rccl_rank = b.comm_count()         # what the communicator itself says (ncclCommCount / ncclCommUserRank)
     recv = None
     if rank == 0:
         recv = torch.empty((2, world, tiles, n, n, 4), dtype=torch.float32, device=dev)
@@ -429,7 +495,8 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
                     "(displacement, normal) in one RCCL group from the library's map buffers to rank 0; 'overlapped' = depth 2, "
                     "the gather of batch j runs on the communication stream beside the synthesis of batch j+1",
             "transport": "RCCL (librccl loaded by libocean_hip.so), ncclGather" + ("; 1 rank: device-local copy, no xGMI traffic" if world == 1 else ""),
-            "tile_size": n, "tiles_per_rank": tiles, "ranks": world, "bytes_per_rank_per_step": per_rank,
+            "tile_size": n, "tiles_per_rank": tiles, "ranks": world, "rccl_ranks_seen": rccl_ranks, "rccl_rank_of_root": rccl_rank,
+            "bytes_per_rank_per_step": per_rank,
             "bytes_into_root_per_step": per_rank * (world - 1),
             "compute_only": {"ms_per_step": compute * 1e3, "tiles_per_s": total / compute},
             "compute_plus_gather_serial": {"ms_per_step": serial * 1e3, "tiles_per_s": total / serial},
@@ -526,6 +593,7 @@ def main():
         _, kern_ms_main = b.time_frames(0.0, DT, 200, nk, per_kernel=True)      # serial frames of THIS context, reported beside
     names = b.kernel_names()
     own_bpt = float(b.algorithmic_bytes_per_texel)
+    kernel_bytes = dict(zip(names, b.algorithmic_bytes_per_launch()))
     b.close()
     torch.cuda.empty_cache()
     # The serial pass runs in a context of its own at depth 1 -- what a caller of the synchronous ComputeWaves has -- and the
@@ -539,7 +607,7 @@ def main():
     ms_serial, kern_ms = bs.time_frames(0.0, DT, 300, nk, per_kernel=True)
     serial_us_per_step = ms_serial / nk * 1e3
     bs.close()
-    roofline = roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, args.depth, ms_per_step, serial_us_per_step, own_bpt)
+    roofline = roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, args.depth, ms_per_step, serial_us_per_step, own_bpt, kernel_bytes)
     roofline["serial_pass"] = "a context of its own at pipeline depth 1 (the synchronous-call configuration), 300 warm-up + 200 timed frames"
     if kern_ms_main is not None:
         roofline["serial_kernels_in_bench_context_us"] = {k: v * 1e3 for k, v in zip(names, kern_ms_main)}
@@ -559,26 +627,7 @@ def main():
         os.write(json_fd, (json.dumps(line_obj) + "\n").encode())
 
     def headline(gather_obj, extra_obj, cpu, cpu_strong):
-        return {
-            "metric": "ocean frames/s (ComputeWaves, 7 fields -> displacement + normal map)",
-            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "prewarm_frames": args.prewarm, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n}x{n} tile, FULL7 (7 real fields via 3.5 complex 2-D iFFTs), "
-                                   f"{tiles} tile(s) per rank per step, reference default parameters",
-                       "tile_size": n, "tiles_per_rank": tiles, "seed": SEED, "dt": DT,
-                       "pipeline_depth": args.depth,
-                       "api": "ocean_compute_waves_async x steps, then ocean_synchronize (frames alternate between "
-                              f"{args.depth} independent chains, each with its own intermediates and map set)",
-                       "parallelism": f"tiles sharded 1 process per GPU x{world}, no data-path collective"},
-            "gtexels_per_s": n * n * frames_per_s * 1e-9,
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "cpu_baseline_strong": cpu_strong,
-            "speedup_vs_cpu_baseline_strong": (frames_per_s / cpu_strong["value"]) if cpu_strong and cpu_strong.get("value") else None,
-            "gather": gather_obj,
-            "extra": extra_obj,
-        }
+        return build_line(args, world, n, tiles, frames_per_s, ms_per_step, roofline, gather_obj, extra_obj, cpu, cpu_strong)
 
     # Everything the contract asks for is measured by now.  What follows at N > 1 -- the gather over xGMI, which no machine
     # available to the builder could run -- must not be able to take the line down with it: if it has not come back after
@@ -588,8 +637,9 @@ def main():
         import threading
 
         def give_up():
+            # the line goes out (the timed region is complete), but the run FAILED: launcher and driver must see it
             emit(headline({"error": "the gather measurement did not finish within 240 s; timed region unaffected"}, {}, None, None))
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(240.0, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -628,21 +678,25 @@ def main():
             extra["4096x4096_fp16_intermediates_depth3"] = measure_config(W, 4096, 1, local_rank, 300, 100, depth=3, inter_bits=16)
             extra["2048x2048_fp16_intermediates_depth3"] = measure_config(W, 2048, 1, local_rank, 1000, 300, depth=3, inter_bits=16)
             extra["1024x1024_batch8_fp16_intermediates_depth2"] = measure_config(W, 1024, 8, local_rank, 500, 150, depth=2, inter_bits=16)
-            # the Jacobian / foam channel (eight fields, 86 B/texel)
+            # the Jacobian / foam channel (eight fields, 85 B/texel)
             extra["2048x2048_jacobian_depth3"] = measure_config(W, 2048, 1, local_rank, 1000, 300, depth=3, mode=3)
         cpu = cpu_strong = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:                # rank 0's host cores, at every N (a child process: no GPU, no process group)
             cpu, cpu_strong = cpu_baseline_isolated(n, args.cpu_seconds)
         out = headline(gather, extra, cpu, cpu_strong)
     emit(out)
+    failed = isinstance(gather, dict) and "error" in gather
     if world > 1:
         import threading
-        t = threading.Timer(60.0, lambda: os._exit(0))      # the line is out: a stuck teardown must not hold the launcher
+        # the line is out: a stuck teardown must not hold the launcher -- but it is a failure, and reported as one
+        t = threading.Timer(300.0, lambda: os._exit(4))     # (rank 0 arrives after its CPU baseline leg: up to ~2 minutes)
         t.daemon = True
         t.start()
         dist.barrier()
         dist.destroy_process_group()
         t.cancel()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

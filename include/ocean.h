@@ -43,7 +43,7 @@ enum {
     OCEAN_E_HIP         = -3,   /* a HIP runtime call failed; see ocean_last_hip_error  */
     OCEAN_E_NOT_READY   = -4,   /* ocean_compute_waves before ocean_prepare             */
     OCEAN_E_NOMEM       = -5,
-    OCEAN_E_UNSUPPORTED = -6,   /* tile size outside [16, 4096]                         */
+    OCEAN_E_UNSUPPORTED = -6,   /* tile size outside [16, 4096]; export of caller-bound maps */
     OCEAN_E_COMM        = -7    /* RCCL call failed / librccl missing; see ocean_last_rccl_error */
 };
 
@@ -173,6 +173,26 @@ int ocean_read_maps_staging(ocean_t* ctx, uint32_t tile, void* mapped_base, size
  * hand-off to a device-side consumer (interop, RCCL gather).                     */
 int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
 
+/* Export of the maps as a dma-buf (the remainder: the reference uploads both maps every frame through a
+ * host-visible staging buffer -- CopyModelTessDataToStagingBuffer + UpdateFrameMaps, WaterSurfaceMesh.cpp:642-755,
+ * vulkan/Texture2D.cpp:175-226: a device-to-host-to-device round trip of N*N*32 bytes, 40 x the synthesis at 2048^2).  One
+ * map set is one device allocation [displacement maps of all tiles | normal maps of all tiles]; this call hands out a
+ * dma-buf file descriptor of it (hipMemGetHandleForAddressRange, hipMemRangeHandleTypeDmaBufFd) that a Vulkan renderer
+ * imports with VK_EXT_external_memory_dma_buf (VkImportMemoryFdInfoKHR, handle type DMA_BUF_BIT_EXT) and binds to a
+ * VkBuffer -- its vkCmdCopyBufferToImage then reads the maps where they were written, bufferOffset = *disp_offset /
+ * *nrm_offset (+ tile * N*N*16) in the place of the staging offsets -- or another process / API imports like any dma-buf
+ * (HIP: hipImportExternalMemory with hipExternalMemoryHandleTypeOpaqueFd; tests/cpp/import_demo.cpp).  INTEGRATION.md
+ * section B has the Vulkan side.
+ *   *dmabuf_fd   a new descriptor per call; the caller closes it.  The memory stays owned by the context and valid until
+ *                ocean_destroy / ocean_set_tile_size.
+ *   *bytes       size of the exported range (the allocation, a whole number of 2 MiB pages >= 2 * tiles * N*N*16).
+ *   *map_set     which of the context's map sets this is: the one of the most recently enqueued frame (set 0 before any
+ *                frame).  At pipeline depth 1 there is only set 0 and one export serves every frame; at depth D frames
+ *                rotate over D sets -- export after each of the first D frames, or keep depth 1 for an importing renderer.
+ * Consumers order themselves with the frames as always: ocean_synchronize / ocean_wait_frame on the host, or an exported
+ * semaphore of their own API.  Caller-bound output (ocean_bind_output) is not exported: OCEAN_E_UNSUPPORTED.            */
+int ocean_export_maps(ocean_t* ctx, int* dmabuf_fd, size_t* disp_offset, size_t* nrm_offset, size_t* bytes, int* map_set);
+
 /* Make the context write its maps into caller-owned device memory
  * (tiles*N*N*4 floats each, 16-byte aligned), e.g. tensors owned by the
  * harness so a collective can send them without a copy.  NULL restores the
@@ -300,6 +320,9 @@ int   ocean_set_stream(ocean_t* ctx, void* hip_stream);
 int ocean_comm_unique_id(void* id_out /* OCEAN_COMM_ID_BYTES */);
 int ocean_comm_init(ocean_t* ctx, int nranks, int rank, const void* id /* OCEAN_COMM_ID_BYTES */);
 int ocean_comm_destroy(ocean_t* ctx);
+/* Size of the context's communicator and this context's rank in it, as RCCL reports them (ncclCommCount,
+ * ncclCommUserRank): what a report of a multi-GPU run should quote instead of the launcher's word.                     */
+int ocean_comm_count(const ocean_t* ctx, int* ranks, int* rank);
 int ocean_gather_maps(ocean_t* ctx, int root, void* d_recv_disp, void* d_recv_nrm);
 /* The same gather with the maps converted to IEEE half on the sending GPU first (round to nearest; 16 instead of 32
  * bytes per texel over xGMI, SURVEY.md 8e's option): the root receives tiles*N*N*4 halves per map and rank.  For
@@ -357,6 +380,9 @@ int ocean_last_launch(const ocean_t* ctx, int idx, ocean_launch_info* out);
  * column and its point mirror share it --, 14 + 14 half-size intermediates out and in, 2 + 2 raw height, 32 maps).  SURVEY.md section 8d prices a plain 3.5-transform
  * two-pass scheme at 108; bench.py reports that figure separately, labelled as a model.     */
 int ocean_algorithmic_bytes_per_texel(const ocean_t* ctx);
+/* The same figure per launch (idx in ocean_kernel_name order; 23 / 28 / 22 for the fp32 seven-field frame): what
+ * bench.py's roofline divides by a kernel's duration.  0 if idx is out of range.                                        */
+int ocean_algorithmic_bytes_per_launch(const ocean_t* ctx, int idx);
 
 #ifdef __cplusplus
 }

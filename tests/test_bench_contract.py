@@ -44,6 +44,44 @@ def test_roofline_object_uses_own_bytes_and_never_exceeds_peak_on_them(bench):
     assert set(r["kernels"]) == set(names)
 
 
+def test_multi_gpu_line_carries_config5_workload_cpu_baseline_and_roofline(bench):
+    """What rank 0 prints at N > 1: the documented config-5 invocation names the workload as BASELINE does,
+    and the line keeps `cpu_baseline` and `roofline` (round 2 dropped both at N > 1)."""
+    a = bench.parse(["--gpus", "8", "--size", "1024", "--tiles", "8", "--depth", "2", "--steps", "100", "--warmup", "20"])
+    names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
+    roof = bench.roofline_object(1024, 8, names, [0.045, 0.04, 0.03], [0.06, 0.05, 0.04], 2, 0.11, 120.0, 73.0,
+                                 dict(zip(names, (23, 28, 22))))
+    cpu = {"value": 20.0, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "synthetic"}
+    gather = {"ranks": 8, "rccl_ranks_seen": 8, "compute_only": {"tiles_per_s": 5e5}}
+    line = bench.build_line(a, 8, 1024, 8, 5.6e5, 0.11, roof, gather, {}, cpu, dict(cpu, value=80.0))
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32"
+    assert line["config"]["workload"].startswith("64 x 1024x1024 tiles, 8 per GPU") and "BASELINE config 5" in line["config"]["workload"]
+    assert line["config"]["tiles_per_rank"] == 8 and line["config"]["pipeline_depth"] == 2
+    assert line["cpu_baseline"]["value"] == 20.0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline_strong"]["value"] == 80.0
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["kernel"] in names
+    assert r["algorithmic_bytes_per_launch"] == r["kernel_bytes_per_texel"][r["kernel"]] * 1024 * 1024 * 8
+    assert line["gather"]["rccl_ranks_seen"] == 8
+    assert line["warmup"] == 20 and line["warmup_frames_effective"] == 20 + a.prewarm
+    json.dumps(line)
+    # a single-GPU single-tile line still names the headline tile
+    one = bench.build_line(bench.parse([]), 1, 2048, 1, 2e4, 0.05, roof, None, {}, cpu, None)
+    assert one["config"]["workload"].startswith("2048x2048 tile")
+
+
+def test_stale_profile_summaries_are_not_quoted(bench, monkeypatch):
+    """traffic / rocprof figures of profiles/*.json enter the line only while the kernel sources hash to what they were measured with."""
+    names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
+    r = bench.roofline_object(2048, 1, names, [0.025, 0.022, 0.0175], None, 1, 0.066, 66.0, 73.0)
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    current = t.get("_kernel_source_sha16") == bench.kernel_source_sha16()
+    assert r["committed_profiles"]["current"] == current
+    assert (r["traffic"] is not None) == current
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda: "0" * 16)
+    r = bench.roofline_object(2048, 1, names, [0.025, 0.022, 0.0175], None, 1, 0.066, 66.0, 73.0)
+    assert r["traffic"] is None and r["rocprof_launch_us"] is None and all("traffic_bytes_per_launch" not in k for k in r["kernels"].values())
+
+
 def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
     ref, strong = bench.cpu_baseline(64, 0.3)
     assert ref["kind"] == "port" and ref["unit"] == "frames/s" and ref["value"] > 0

@@ -303,13 +303,18 @@ def test_bench_self_launcher_starts_n_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["OCEAN_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm", "20",
-                        "--size", "512", "--no-extra", "--no-cpu-baseline", "--no-gather"], capture_output=True, text=True, env=env, timeout=600)
+                        "--size", "512", "--tiles", "2", "--depth", "2", "--no-extra", "--cpu-seconds", "0.4", "--no-gather"],
+                       capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                       # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["roofline"]["frac"] < 1.0 and out["roofline"]["frame_frac"] < 1.0
+    # the N > 1 line keeps the CPU baseline (rank 0's host) and names the sharded workload (config 5's shape: T tiles per GPU)
+    assert out["config"]["workload"].startswith("4 x 512x512 tiles, 2 per GPU") and out["config"]["tiles_per_rank"] == 2
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1
+    assert out["warmup"] == 5 and out["warmup_frames_effective"] == 25
 
 
 def test_readout_paths_under_pipelining_refer_to_the_last_frame():

@@ -41,12 +41,13 @@ def test_bench_two_gpus_over_rccl():
     if _gpus() < 2:
         pytest.skip("needs 2 GPUs")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "50", "--prewarm", "100",
-                        "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(), timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+                        "--no-extra", "--cpu-seconds", "1"], capture_output=True, text=True, env=_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]          # a gather that fails or hangs exits non-zero (bench.py: give_up / failed)
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["cpu_baseline"]["value"] > 0
     g = out["gather"]
-    assert g["ranks"] == 2 and g["root_copy_matches_local_maps"] is True
+    assert "error" not in g
+    assert g["ranks"] == 2 and g["rccl_ranks_seen"] == 2 and g["root_copy_matches_local_maps"] is True
     assert g["compute_only"]["tiles_per_s"] > g["compute_plus_gather_serial"]["tiles_per_s"] > 0
 
 
@@ -58,6 +59,20 @@ def _build_gather_demo(tmp_path):
                     "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "cpp", "gather_demo.cpp"), "-o", str(exe),
                     "-L", lib_dir, "-locean_hip", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return exe
+
+
+def test_bench_config5_invocation_on_eight_gpus():
+    """BASELINE config 5 as the timed workload: `bench.py --gpus 8 --size 1024 --tiles 8 --depth 2`."""
+    if _gpus() < 8:
+        pytest.skip("needs 8 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--size", "1024", "--tiles", "8", "--depth", "2",
+                        "--steps", "200", "--warmup", "50", "--prewarm", "100", "--no-extra", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, env=_env(), timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and "BASELINE config 5" in out["config"]["workload"] and out["value"] > 0
+    assert "error" not in out["gather"] and out["gather"]["rccl_ranks_seen"] == 8 and out["gather"]["root_copy_matches_local_maps"] is True
+    assert out["roofline"]["frac"] < 1.0 and out["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.parametrize("ranks", [1, 2, 8])

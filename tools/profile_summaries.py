@@ -27,11 +27,24 @@ def load(name):
 
 
 def save(name, d):
+    # the hash of the kernel sources these figures were measured with: bench.py quotes them only while it matches
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.kernel_source_sha16()
+    if d.get("_kernel_source_sha16") not in (None, sha):
+        d = {k: v for k, v in d.items() if k.startswith("_") or v.get("kernel_source_sha16") == sha}     # drop entries of older kernels
+    d["_kernel_source_sha16"] = sha
     json.dump(d, open(os.path.join(ROOT, "profiles", name), "w"), indent=1, sort_keys=True)
 
 
 def rel(p):
     return os.path.relpath(os.path.abspath(p), ROOT)
+
+
+def _sha():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.kernel_source_sha16()
 
 
 def kernel_of(full):
@@ -50,7 +63,8 @@ def stats(path, tiles=1):
         a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
     for (k, n), (calls, total) in acc.items():
         key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
-        out[key] = {"avg_us": total / calls * 1e-3, "calls": calls, "source": rel(path) + " (rocprofv3 --kernel-trace --stats, serial frames)"}
+        out[key] = {"avg_us": total / calls * 1e-3, "calls": calls, "source": rel(path) + " (rocprofv3 --kernel-trace --stats, serial frames)",
+                    "kernel_source_sha16": _sha()}
     save("kernel_stats.json", out)
 
 
@@ -71,7 +85,8 @@ def traffic(path, n, tiles=1, fetch_factor=2.0):
         key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
         ent = {"hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * fetch_factor + v["WRITE_SIZE"] * 1024),
                "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"], "fetch_factor": fetch_factor,
-               "source": rel(path) + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)"}
+               "source": rel(path) + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)",
+               "kernel_source_sha16": _sha()}
         if k == "k_zpass":
             ent["correction"] = (f"FETCH_SIZE x {fetch_factor}: its loads are coalesced (16 / 4 bytes per lane), for which "
                                  "tools/ubench/fetchcal.hip measures known bytes / FETCH_SIZE = 2.000 (128-byte requests tallied at 64: "

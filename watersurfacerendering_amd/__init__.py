@@ -168,6 +168,12 @@ class OceanBatch:
         buf = C.create_string_buffer(unique_id, _abi.OCEAN_COMM_ID_BYTES)
         _abi.check(self._L.ocean_comm_init(self._h, nranks, rank, buf), "ocean_comm_init")
 
+    def comm_count(self):
+        """(ranks, rank) of the context's communicator as RCCL reports them."""
+        n, r = C.c_int(), C.c_int()
+        _abi.check(self._L.ocean_comm_count(self._h, C.byref(n), C.byref(r)), "ocean_comm_count")
+        return n.value, r.value
+
     def comm_destroy(self):
         _abi.check(self._L.ocean_comm_destroy(self._h), "ocean_comm_destroy")
 
@@ -225,6 +231,13 @@ class OceanBatch:
             out_d.append(d[off:off + w * w].reshape(w, w, 4)); out_q.append(q[off:off + w * w].reshape(w, w, 4))
             off += w * w; w //= 2
         return out_d, out_q
+
+    def export_maps(self):
+        """dma-buf of the current map set (ocean_export_maps): (fd, disp_offset, nrm_offset, bytes, map_set); close the fd yourself."""
+        fd, ms = C.c_int(-1), C.c_int(0)
+        do, no, nb = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _abi.check(self._L.ocean_export_maps(self._h, C.byref(fd), C.byref(do), C.byref(no), C.byref(nb), C.byref(ms)), "ocean_export_maps")
+        return fd.value, do.value, no.value, nb.value, ms.value
 
     def bind_output(self, d_disp: int | None, d_nrm: int | None):
         _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")
@@ -290,6 +303,10 @@ class OceanBatch:
     @property
     def algorithmic_bytes_per_texel(self) -> int:
         return int(self._L.ocean_algorithmic_bytes_per_texel(self._h))
+
+    def algorithmic_bytes_per_launch(self):
+        """Bytes per texel of each of the three launches, in kernel_names() order (sums to algorithmic_bytes_per_texel)."""
+        return [int(self._L.ocean_algorithmic_bytes_per_launch(self._h, i)) for i in range(3)]
 
 
 def comm_unique_id() -> bytes:

@@ -34,12 +34,12 @@ SYMBOLS = [
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_frame_tracking", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
-    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_bind_output",
-    "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
+    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_export_maps", "ocean_bind_output",
+    "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_comm_count", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
     "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
     "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
-    "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel",
+    "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
 ]
 
 OCEAN_LAUNCH_NT_MAPS, OCEAN_LAUNCH_NT_INTER, OCEAN_LAUNCH_HALF_INTER, OCEAN_LAUNCH_JACOBIAN = 1, 2, 4, 8
@@ -131,11 +131,13 @@ def lib() -> C.CDLL:
         "ocean_comm_unique_id": (i32, [C.c_void_p]),
         "ocean_comm_init": (i32, [P, i32, i32, C.c_void_p]),
         "ocean_comm_destroy": (i32, [P]),
+        "ocean_comm_count": (i32, [P, C.POINTER(i32), C.POINTER(i32)]),
         "ocean_gather_maps": (i32, [P, i32, C.c_void_p, C.c_void_p]),
         "ocean_gather_maps_f16": (i32, [P, i32, C.c_void_p, C.c_void_p]),
         "ocean_last_rccl_error": (i32, []),
         "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
         "ocean_bind_output": (i32, [P, P, P]),
+        "ocean_export_maps": (i32, [P, C.POINTER(i32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32)]),
         "ocean_displace_grid": (i32, [P, u32, u32, f32, f32, f32]),
         "ocean_displace_grid_cascades": (i32, [P, u32, u32, u32, f32, FP, f32]),
         "ocean_read_grid": (i32, [P, C.c_void_p, C.c_void_p]),
@@ -157,6 +159,7 @@ def lib() -> C.CDLL:
         "ocean_kernel_name": (C.c_char_p, [P, i32]),
         "ocean_last_launch": (i32, [P, i32, C.POINTER(LaunchInfo)]),
         "ocean_algorithmic_bytes_per_texel": (i32, [P]),
+        "ocean_algorithmic_bytes_per_launch": (i32, [P, i32]),
     }
     for name, (res, args) in sig.items():
         try:

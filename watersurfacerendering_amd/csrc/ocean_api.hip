@@ -48,7 +48,7 @@ static void free_device(ocean_ctx* c)
 
 static void free_set(ocean_ctx* c, int i)
 {
-    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->z3[i], c->jraw[i], c->jac0[i], c->minmax[i], c->done_ctr[i], c->dispN[i], c->nrmN[i]};
+    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->z3[i], c->jraw[i], c->jac0[i], c->minmax[i], c->done_ctr[i], c->dispN[i]};   // (nrmN: same allocation)
     for (void* b : per) if (b) (void)hipFree(b);
     if (c->done_rec[i]) (void)hipHostFree(c->done_rec[i]);
     for (auto& p : c->pack_half[i]) if (p) { (void)hipFree(p); p = nullptr; }
@@ -78,8 +78,11 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     HIP_TRY(hipHostMalloc((void**)&c->done_rec[i], t * sizeof(uint4), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->done_rec[i], 0, t * sizeof(uint4));
     c->seq[i] = 0;
-    HIP_TRY(hipMalloc(&c->dispN[i], t * n2 * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->nrmN[i], t * n2 * sizeof(float4)));
+    // both maps of the set in ONE allocation [displacement | normal] -- the range ocean_export_maps hands out as one dma-buf,
+    // in the order the reference lays its staging buffer out (WaterSurfaceMesh.cpp:736-738); a whole number of 2 MiB pages
+    c->maps_bytes[i] = (2 * t * n2 * sizeof(float4) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    HIP_TRY(hipMalloc(&c->dispN[i], c->maps_bytes[i]));
+    c->nrmN[i] = c->dispN[i] + t * n2;
     return OCEAN_OK;
 }
 
@@ -179,7 +182,7 @@ const char* ocean_strerror(int code)
         case OCEAN_E_HIP: return "HIP runtime error";
         case OCEAN_E_NOT_READY: return "ocean_prepare has not been called";
         case OCEAN_E_NOMEM: return "out of memory";
-        case OCEAN_E_UNSUPPORTED: return "tile size must be a power of two in [16, 4096]";
+        case OCEAN_E_UNSUPPORTED: return "unsupported (tile size must be a power of two in [16, 4096]; no export of caller-bound maps)";
         case OCEAN_E_COMM: return "RCCL error (or librccl could not be loaded); see ocean_last_rccl_error";
         default: return "unknown error";
     }
@@ -719,6 +722,27 @@ int ocean_device_maps(ocean_t* c, void** d_disp, void** d_nrm)
     return OCEAN_OK;
 }
 
+int ocean_export_maps(ocean_t* c, int* dmabuf_fd, size_t* disp_offset, size_t* nrm_offset, size_t* bytes, int* map_set)
+{
+    if (!c || !dmabuf_fd) return OCEAN_E_INVALID;
+    *dmabuf_fd = -1;
+    if (c->ext_disp || c->ext_nrm) return OCEAN_E_UNSUPPORTED;          // caller-bound output: the caller owns (and exports) that memory
+    HIP_TRY(hipSetDevice(c->device));
+    const int set = c->have_frame ? c->last_set : 0;
+    {
+        int rc_ = alloc_set(c, set);
+        if (rc_) return rc_;
+    }
+    int fd = -1;
+    HIP_TRY(hipMemGetHandleForAddressRange(&fd, (hipDeviceptr_t)c->dispN[set], c->maps_bytes[set], hipMemRangeHandleTypeDmaBufFd, 0));
+    *dmabuf_fd = fd;
+    if (disp_offset) *disp_offset = 0;
+    if (nrm_offset) *nrm_offset = (size_t)c->tiles * c->n * c->n * sizeof(float4);
+    if (bytes) *bytes = c->maps_bytes[set];
+    if (map_set) *map_set = set;
+    return OCEAN_OK;
+}
+
 int ocean_bind_output(ocean_t* c, void* d_disp, void* d_nrm)
 {
     if (!c) return OCEAN_E_INVALID;
@@ -1085,6 +1109,22 @@ const char* ocean_kernel_name(const ocean_t* c, int idx)
     return c ? kernel_name_of(idx) : nullptr;
 }
 
+int ocean_algorithmic_bytes_per_launch(const ocean_t* c, int idx)
+{
+    // the split of ocean_algorithmic_bytes_per_texel over the three launches (fp32 FULL7: 23 / 28 / 22):
+    //   z pass       spectrum 8 (4 as half2) + dispersion 1 (2 as fp32) in, 14 of intermediates out (7 as half2; 16 / 8 with pair 3)
+    //   x pass, b    pairs 1, 2 and the height plane 10 in (5; pair 3: 12 / 6), raw height 2 + normal map 16 out (+ 4: the Jacobian's two planes)
+    //   x pass, disp pair 0 and the raw height 4 + 2 in (2 + 2; + 4 of the two planes), displacement map 16 out
+    if (idx < 0 || idx > 2) return 0;
+    const bool half = c && c->inter_bits == 16, jac = c && c->mode == OCEAN_MODE_JACOBIAN;
+    const int h0 = (c && c->h0_bits == 16) ? 4 : 8, w = (c && c->prepared && !c->omega16) ? 2 : 1;
+    const int z_out = jac ? (half ? 8 : 16) : (half ? 7 : 14);
+    const int pair0 = half ? 2 : 4;
+    if (idx == 0) return h0 + w + z_out;
+    if (idx == 1) return (z_out - pair0) + 2 + 16 + (jac ? 4 : 0);
+    return pair0 + 2 + 16 + (jac ? 4 : 0);
+}
+
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)
 {
     // what THIS pipeline has to move per texel in the seven-field fp32 mode (ocean_kernels.h):
@@ -1111,6 +1151,8 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     bool ok = false;
 };
 RcclApi& rccl()
@@ -1126,6 +1168,8 @@ RcclApi& rccl()
         a.GroupStart = (decltype(a.GroupStart))dlsym(a.so, "ncclGroupStart");
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.so, "ncclGroupEnd");
         a.Gather = (decltype(a.Gather))dlsym(a.so, "ncclGather");
+        a.CommCount = (decltype(a.CommCount))dlsym(a.so, "ncclCommCount");
+        a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.so, "ncclCommUserRank");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Gather;
         return a;
     }();
@@ -1181,6 +1225,20 @@ int ocean_comm_init(ocean_t* c, int nranks, int rank, const void* id_in)
     HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (auto& e : c->frame_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->gather_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return OCEAN_OK;
+}
+
+int ocean_comm_count(const ocean_t* c, int* ranks, int* rank)
+{
+    // what the communicator itself reports (ncclCommCount / ncclCommUserRank), not what ocean_comm_init was told
+    if (!c) return OCEAN_E_INVALID;
+    if (!c->comm) return OCEAN_E_NOT_READY;
+    if (!rccl().CommCount || !rccl().CommUserRank) return OCEAN_E_COMM;
+    int n = 0, r = -1;
+    RCCL_TRY(rccl().CommCount(c->comm, &n));
+    RCCL_TRY(rccl().CommUserRank(c->comm, &r));
+    if (ranks) *ranks = n;
+    if (rank) *rank = r;
     return OCEAN_OK;
 }
 

@@ -59,8 +59,9 @@ struct ocean_ctx {
                                     //   ocean_wait_frame polls); otherwise the records only carry the height keys and the wait is a stream synchronisation
     bool track_async = false;       // ocean_set_frame_tracking: asynchronous frames are tracked too (the synchronous call always is)
     unsigned seq[MAXD] = {};        // sequence number of the chain's most recently enqueued frame (0: none since the buffers exist)
-    float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use)
-    float4* nrmN[MAXD] = {};
+    float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use): ONE allocation per set,
+    float4* nrmN[MAXD] = {};       //   [displacement maps of all tiles | normal maps of all tiles] (nrmN points into dispN's)
+    size_t maps_bytes[MAXD] = {};  // size of that allocation (a whole number of 2 MiB pages: ocean_export_maps)
     float4* ext_disp = nullptr;
     float4* ext_nrm = nullptr;
     float* toff = nullptr;
