@@ -1485,12 +1485,17 @@ OCEAN_GEO(32, 64, Plan<32>, 4, 64, Plan<32>)
 OCEAN_GEO(64, 64, Plan<64>, 4, 64, Plan<64>)
 OCEAN_GEO(128, 64, Plan<128>, 4, 64, Plan<128>)
 OCEAN_GEO(256, 64, Plan<256>, 4, 64, Plan<256>)
+// (x pass at 512^2 with twice the threads per transform -- 512 threads, radix 4.4.4.8 -- or with two rows per workgroup and twice the
+// workgroups: both within the noise of this form, 16.5-17.5 us per serial frame; profiles/r03_small_tile_experiments.txt)
 OCEAN_GEO(512, (zpass_columns<512>() == 4 ? 256 : 128), Plan<512>, 4, 256, Plan<512>)
 // from 1024 up the z pass runs radix-8 butterflies with twice the threads (one more LDS
 // exchange, about half the VGPRs): -9 % at 1024, -1.5 % at 2048, -4.5 % at 4096
 OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), 4, 256, Plan<1024>)
 // (x pass with two rows per workgroup and 256 threads -- 106 VGPRs, four workgroups per CU instead of one -- is 15 % slower at 2048
 // and 1024: 16- instead of 32-byte pieces of the intermediates; profiles/r02_layout_experiments.txt)
+// (256 threads with two butterflies per thread and stage -- 124 VGPRs, and with the S+ / kz tables out of LDS four workgroups per
+// CU, i.e. 1024 of the 1025 columns in ONE round -- is no faster: 26.4-26.7 us for 1024 workgroups against 25.2-26.5 with 512 threads
+// at three per CU; the z pass is bound by what a CU gets through, not by the round structure: profiles/r03_zpass_experiments.txt)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), 4, 512, Plan<2048>)
 OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), 2, 512, Plan<4096>)
 #undef OCEAN_GEO

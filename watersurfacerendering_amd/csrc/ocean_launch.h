@@ -91,8 +91,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             const unsigned rest = gx % slots;
             if (gx > slots && rest != 0 && 2 * rest <= slots) { za.zfull = (int)(gx - rest); gx = (gx - rest) + 2 * rest; split = true; }
         }
-#ifdef OCEAN_STAMPS
-        if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid
+#if defined(OCEAN_STAMPS) || defined(OCEAN_DEVELOPER)
+        if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
 #endif
         const dim3 grid(gx, tiles), block(G::T_ROWS);
         {
