@@ -312,7 +312,12 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
     constexpr int ITEMS = (N / R) * C;
     constexpr int IT = (ITEMS + T - 1) / T;
     constexpr bool GUARD = (ITEMS % T) != 0;
-    v2* ldsv = reinterpret_cast<v2*>(lds);
+    // volatile: keeps every exchange access a ds_read_b64 / ds_write_b64 of its own.  With a shared base register and immediate
+    // offsets the compiler otherwise pairs them into ds_read2(st64)_b64 / ds_write2_b64, which run at HALF the LDS rate and map to 32
+    // instead of 64 banks -- the padding of the image is laid out for the latter: bank-conflict cycles doubled in all three kernels
+    // (PMC: profiles/r03_lds_experiments.txt).
+    typedef __attribute__((address_space(3))) volatile v2 lds_v2;      // (explicitly LDS: a volatile generic pointer would turn into flat accesses)
+    lds_v2* ldsv = (lds_v2*)lds;
     if constexpr (LAST) {
         // nothing is written back to LDS: finish one work item at a time (R complex live, not IT*R)
 #pragma unroll
