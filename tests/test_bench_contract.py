@@ -95,6 +95,7 @@ def test_committed_profile_summaries_match_the_kernels(bench):
     must name the kernels bench.py accounts for, and the measured traffic must stay near the algorithmic bytes."""
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert {k + "@2048" for k in bench.KERNEL_BYTES_ACTUAL} <= set(t)
+    assert t["_kernel_source_sha16"] == bench.kernel_source_sha16(), "profiles/*.json were measured with other kernel sources: regenerate (tools/prof_round.sh, pmc3.sh, profile_summaries.py)"
     n2 = 2048 * 2048
     for k in bench.KERNEL_BYTES_ACTUAL:
         v = t[k + "@2048"]
@@ -135,11 +136,11 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The roofline fractions of the committed default bench line (profiles/r02y_bench_default.json) can be recomputed from
-    the committed rocprofv3 summary (profiles/kernel_stats.json <- r02y_kernel_stats_2048_bench_depth1.csv) and the byte
+    """The roofline fractions of the committed default bench line (profiles/r03z_bench_default.json) can be recomputed from
+    the committed rocprofv3 summary (profiles/kernel_stats.json <- r03z_kernel_stats_2048_bench_depth1.csv) and the byte
     accounting of this file: every kernel within 6 %, nothing above 1, and the summaries regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    line = [l for l in open(os.path.join(prof, "r02y_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(prof, "r03z_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
@@ -155,7 +156,7 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r02y_kernel_stats_2048_bench_depth1.csv"))):
+    for row in csv.DictReader(open(os.path.join(prof, "r03z_kernel_stats_2048_bench_depth1.csv"))):
         m = re.search(r"(k_[a-z_]+)<2048", row["Name"])
         if m and m.group(1) in bench.KERNEL_BYTES_ACTUAL:
             a = acc.setdefault(m.group(1), [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
