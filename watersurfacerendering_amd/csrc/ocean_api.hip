@@ -929,8 +929,7 @@ int ocean_set_stream(ocean_t* c, void* s)
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
-    c->user = (hipStream_t)s;
-    c->last_set = 0;
+    c->user = (hipStream_t)s;          // (last_set stays: the most recent frame's maps and records remain the ones read out)
     return OCEAN_OK;
 }
 

@@ -875,9 +875,8 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 // Two batches of two interleaved transforms over e: {pair 0, pair 1}, {pair 2, height};
 // output index p = z position; stored per column nb as side 0 (p <= N/2) / side 1 (N-p).
 // ============================================================================
-// minimum waves per SIMD asked of the register allocator: 2048 fits 80 VGPRs without a
-// spill, i.e. three 512-thread workgroups per CU instead of two (z pass 35.6 -> 30 us);
-// 1024 and 4096 would spill at that cap and keep the looser one
+// minimum waves per SIMD asked of the register allocator: three 512-thread workgroups per CU at 2048 (since round 3 the kernel
+// needs 62 VGPRs and would fit four, but its 51 KB of LDS allow three); 1024 and 4096 keep the looser bound
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
 // (two columns per workgroup at 2048: 59 KB of LDS allow two workgroups per CU, i.e. four waves per SIMD and 128 VGPRs; the
 //  80-VGPR cap of the one-column form would only make that variant spill)
