@@ -313,8 +313,8 @@ def kernel_source_sha16() -> str:
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "watersurfacerendering_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip")):
+    for f in sorted(os.listdir(csrc)):      # the device code and the frame launcher (not the host side of the ABI, ocean_api.hip)
+        if f in ("ocean_kernels.h", "fft_engine.h", "ocean_launch.h") or (f.startswith("frames_") and f.endswith(".hip")):
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 

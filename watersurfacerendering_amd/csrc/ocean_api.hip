@@ -1103,6 +1103,17 @@ int ocean_last_launch(const ocean_t* c, int idx, ocean_launch_info* out)
     return OCEAN_OK;
 }
 
+#ifdef OCEAN_DEVELOPER
+// developer builds only: device addresses of chain `set`'s buffers (placement probes, tools/xb_placement.py)
+int ocean_debug_buffers(ocean_t* c, int set, void** out /* [8]: h0, omega_q, z, zh, hraw, minmax, disp, nrm */)
+{
+    if (!c || !out || set < 0 || set >= MAXD) return OCEAN_E_INVALID;
+    void* v[8] = {c->h0, c->omega_q, c->z[set], c->zh[set], c->hraw[set], c->minmax[set], c->dispN[set], c->nrmN[set]};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return OCEAN_OK;
+}
+#endif
+
 const char* ocean_kernel_name(const ocean_t* c, int idx)
 {
     return c ? kernel_name_of(idx) : nullptr;
