@@ -239,3 +239,25 @@ def test_exported_maps_are_read_by_another_process_through_the_dmabuf(tmp_path):
     assert e.value.code == _abi.OCEAN_E_UNSUPPORTED
     b.bind_output(None, None)
     b.close()
+
+
+def test_python_mirror_async_pair_matches_the_blocking_call():
+    """WSTessendorf.ComputeWavesAsync() / Wait() (the mirror of include/WSTessendorf.hpp's opt-in pair): A at once, the previous frame's maps
+    until Wait(), then exactly the blocking call's frame."""
+    import watersurfacerendering_amd as W
+    ws = W.WSTessendorf(256, 1000.0)
+    ws.Prepare(seed=21)
+    a0 = ws.ComputeWaves(0.5)
+    d0 = ws.GetDisplacements().copy()
+    a1 = ws.ComputeWavesAsync(1.5)
+    assert a1 != a0 and np.array_equal(ws.GetDisplacements(), d0)          # the front pair is still the previous frame
+    ws.Wait()
+    d1, q1, mn1, mx1 = ws.GetDisplacements().copy(), ws.GetNormals().copy(), ws.GetMinHeight(), ws.GetMaxHeight()
+    assert not np.array_equal(d1, d0)
+    assert ws.ComputeWaves(1.5) == a1
+    assert np.array_equal(ws.GetDisplacements(), d1) and np.array_equal(ws.GetNormals(), q1)
+    assert (ws.GetMinHeight(), ws.GetMaxHeight()) == (mn1, mx1)
+    for j in range(5):                                                     # back to back: each call waits for the one before
+        ws.ComputeWavesAsync(2.0 + j)
+    ws.Wait()
+    assert ws.ComputeWaves(6.0) == pytest.approx(ws.ComputeWaves(6.0))

@@ -353,6 +353,8 @@ class WSTessendorf:
         self._min = -1.0   # WSTessendorf.h:227-228
         self._max = 1.0
         self._seed_ctr = 0
+        self._back = None      # pinned back pair of ComputeWavesAsync
+        self._pending = None   # (A, min, max) of a ComputeWavesAsync whose copy has not been waited for
 
     # -- Prepare / ComputeWaves (WSTessendorf.cpp:36-58, 284-455) -------------------
     def Prepare(self, seed: int | None = None, xi: np.ndarray | None = None):
@@ -360,6 +362,8 @@ class WSTessendorf:
             import time
             self._seed_ctr += 1
             seed = (time.time_ns() ^ (self._seed_ctr * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        if self._pending is not None:
+            self.Wait()
         self._b.prepare(seed, xi)
         n = self._b.tile_size
         self._disp = np.zeros((n, n, 4), dtype=np.float32)            # .cpp:48-51
@@ -367,11 +371,58 @@ class WSTessendorf:
         self._nrm[..., 1] = 1.0                                        # .cpp:53-54
 
     def ComputeWaves(self, time: float) -> float:
+        if self._pending is not None:
+            self.Wait()
         amp = float(self._b.compute_waves(time)[0])
         d, q = self._b.read_maps(0, 1)
         self._disp, self._nrm = d[0], q[0]
         _, self._min, self._max = self._b.heights(0)
         return amp
+
+    # -- opt-in non-blocking pair (include/WSTessendorf.hpp: ComputeWavesAsync / Wait; the reference's DOUBLE_BUFFERED idea,
+    #    WaterSurfaceMesh.h:26-34, on the synthesis side) ---------------------------------------------------------------------
+    def ComputeWavesAsync(self, time: float) -> float:
+        """Enqueue the frame and the DMA of both maps into a back pair of pinned arrays; return A as soon as the frame's kernels
+        are done (ocean_wait_frame).  GetDisplacements() / GetNormals() keep returning the previous frame until Wait()."""
+        if self._pending is not None:
+            self.Wait()
+        n = self._b.tile_size
+        if self._back is None or self._back[0].shape[1] != n:
+            self._release_back()
+            self._back = (np.zeros((1, n, n, 4), np.float32), np.zeros((1, n, n, 4), np.float32))
+            for a in self._back:
+                host_register(a)
+            self._b.set_frame_tracking(True)
+        self._b.compute_waves_async(time)
+        self._b.read_maps_async(self._back[0], self._back[1])
+        amp = float(self._b.wait_frame()[0])
+        self._pending = self._b.heights(0)
+        return amp
+
+    def Wait(self):
+        if self._pending is None:
+            return
+        self._b.synchronize()
+        self._disp, self._nrm = self._back[0][0].copy(), self._back[1][0].copy()
+        _, self._min, self._max = self._pending
+        self._pending = None
+
+    def _release_back(self):
+        if getattr(self, "_back", None) is not None:
+            for a in self._back:
+                try:
+                    host_unregister(a)
+                except Exception:
+                    pass
+        self._back = None
+
+    def __del__(self):
+        try:
+            if self._pending is not None:
+                self._b.synchronize()
+            self._release_back()
+        except Exception:
+            pass
 
     # -- getters (WSTessendorf.h:82-107) ----------------------------------------------
     def GetTileSize(self): return self._b.tile_size
@@ -398,6 +449,8 @@ class WSTessendorf:
     def SetTileSize(self, size: int):
         if not _is_pow2(size):
             return                      # .cpp:463-467: ignored
+        if self._pending is not None:
+            self.Wait()
         self._b.set_tile_size(size)
 
     def SetTileLength(self, length: float): self._b.set_params(tile_length=length)
