@@ -181,3 +181,29 @@ def test_cpp_gather_host_builds_and_fails_loudly_without_a_gpu(abi, tmp_path):
         r = subprocess.run([str(exe), "1", "64", "2", "2"], capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "GATHER_OK" not in r.stdout
         assert "RCCL error" in r.stderr or "no usable HIP device" in r.stderr
+
+
+def test_cpp_dmabuf_importer_builds(tmp_path):
+    """tests/cpp/import_demo.cpp (the importing side of ocean_export_maps, run by the GPU tests) must compile and link on every CPU run; without
+    a GPU it fails loudly on its first HIP call."""
+    exe = tmp_path / "import_demo"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    os.path.join(ROOT, "tests", "cpp", "import_demo.cpp"), "-o", str(exe), "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe), "0", "4096", "0", "2048", "2048", str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "IMPORT_OK" not in r.stdout
+
+
+def test_export_and_tracking_fail_loudly_without_a_device(abi):
+    """The round-3 entry points follow the ABI's error convention on bad arguments (no device needed)."""
+    L = abi.lib()
+    fd = C.c_int(7)
+    assert L.ocean_export_maps(None, C.byref(fd), None, None, None, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_wait_frame(None, None) == abi.OCEAN_E_INVALID and L.ocean_set_frame_tracking(None, 1) == abi.OCEAN_E_INVALID
+    li = abi.LaunchInfo()
+    assert L.ocean_last_launch(None, 0, C.byref(li)) == abi.OCEAN_E_INVALID
+    assert L.ocean_comm_count(None, None, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_algorithmic_bytes_per_launch(None, 0) == 23 and L.ocean_algorithmic_bytes_per_launch(None, 1) == 28
+    assert L.ocean_algorithmic_bytes_per_launch(None, 2) == 22 and L.ocean_algorithmic_bytes_per_launch(None, 3) == 0
