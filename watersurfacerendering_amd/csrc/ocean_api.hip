@@ -607,6 +607,7 @@ int ocean_wait_frame(ocean_t* c, float* out_amp)
 {
     if (!c) return OCEAN_E_INVALID;
     if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
     const int rc = wait_frame(c, c->last_set);
     if (rc) return rc;
     if (out_amp)
@@ -640,6 +641,7 @@ int ocean_get_heights(ocean_t* c, uint32_t tile, float* amp, float* min_h, float
     if (!c || tile >= c->tiles) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
     if (!c->have_frame) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
     int rc = wait_frame(c, c->last_set);
     if (rc) return rc;
     const float a = amp_of(c, tile, min_h, max_h);
