@@ -198,6 +198,12 @@ int ocean_export_maps(ocean_t* ctx, int* dmabuf_fd, size_t* disp_offset, size_t*
  * harness so a collective can send them without a copy.  NULL restores the
  * internal buffers.                                                              */
 int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
+/* The other direction of ocean_export_maps: the RENDERER owns the memory.  It exports a VkDeviceMemory (or any device allocation) as a
+ * dma-buf / opaque fd (vkGetMemoryFdKHR), and the context imports it (hipImportExternalMemory) and writes its maps straight into it at
+ * the given byte offsets -- tiles*N*N*16 bytes each, 16-byte aligned, not overlapping, inside `bytes`.  Everything said for
+ * ocean_bind_output holds (depth 1, no ocean_export_maps of such a context); the descriptor stays the caller's (the import holds its own
+ * reference); ocean_bind_output(ctx, NULL, NULL), a resize or ocean_destroy end the binding.                                            */
+int ocean_bind_output_dmabuf(ocean_t* ctx, int dmabuf_fd, size_t bytes, size_t disp_offset, size_t nrm_offset);
 
 /* Output mode.  OCEAN_MODE_FULL7 (default) is the reference: all seven fields.  The
  * reduced modes of BASELINE.json / SURVEY.md 8d compute fewer transforms and leave the

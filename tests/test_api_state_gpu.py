@@ -261,3 +261,40 @@ def test_python_mirror_async_pair_matches_the_blocking_call():
         ws.ComputeWavesAsync(2.0 + j)
     ws.Wait()
     assert ws.ComputeWaves(6.0) == pytest.approx(ws.ComputeWaves(6.0))
+
+
+def test_maps_written_into_memory_another_process_owns(tmp_path):
+    """ocean_bind_output_dmabuf, the other direction of the interop: the renderer owns the memory and hands a dma-buf in.  Here this process
+    owns it (a context's exported map set stands in for a VkDeviceMemory), a CHILD process imports the descriptor, binds it as its output and
+    synthesises a frame into it; this process then finds exactly that frame's maps in its own memory."""
+    import os
+    import subprocess
+    import sys
+    import watersurfacerendering_amd as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, tiles, seed, t = 256, 2, SEED + 77, 2.75
+    owner = W.OceanBatch(n, tiles, 0)                  # only its memory is used: [displacement maps | normal maps]
+    owner.prepare(1)
+    owner.compute_waves(0.0)
+    fd, doff, noff, nbytes, _ = owner.export_maps()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "dmabuf_writer.py"), str(fd), str(nbytes), str(doff), str(noff),
+                            str(n), str(tiles), str(seed), str(t)], pass_fds=(fd,), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "WRITER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+        got_d, got_q = owner.read_maps()               # the owner's map memory, read through the owner
+        ref = W.OceanBatch(n, tiles, 0)
+        ref.prepare(seed)
+        amp = ref.compute_waves(t)
+        d, q = ref.read_maps()
+        assert np.array_equal(got_d, d) and np.array_equal(got_q, q)
+        assert [float(x) for x in r.stdout.split("WRITER_OK")[1].split()] == [float(a) for a in amp]
+        ref.close()
+    finally:
+        os.close(fd)
+    # bad arguments are refused before anything is imported
+    from watersurfacerendering_amd import _abi
+    L = _abi.lib()
+    assert L.ocean_bind_output_dmabuf(owner._h, -1, 1 << 20, 0, 0) == _abi.OCEAN_E_INVALID
+    assert L.ocean_bind_output_dmabuf(owner._h, 0, 16, 0, 0) == _abi.OCEAN_E_INVALID              # too small for the maps
+    assert L.ocean_bind_output_dmabuf(owner._h, 0, nbytes, 0, 64) == _abi.OCEAN_E_INVALID         # overlapping maps
+    owner.close()

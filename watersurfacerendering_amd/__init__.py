@@ -239,6 +239,10 @@ class OceanBatch:
         _abi.check(self._L.ocean_export_maps(self._h, C.byref(fd), C.byref(do), C.byref(no), C.byref(nb), C.byref(ms)), "ocean_export_maps")
         return fd.value, do.value, no.value, nb.value, ms.value
 
+    def bind_output_dmabuf(self, fd: int, nbytes: int, disp_offset: int, nrm_offset: int):
+        """Write the maps into memory another owner exported as a dma-buf (ocean_bind_output_dmabuf)."""
+        _abi.check(self._L.ocean_bind_output_dmabuf(self._h, fd, nbytes, disp_offset, nrm_offset), "ocean_bind_output_dmabuf")
+
     def bind_output(self, d_disp: int | None, d_nrm: int | None):
         _abi.check(self._L.ocean_bind_output(self._h, C.c_void_p(d_disp), C.c_void_p(d_nrm)), "ocean_bind_output")
 

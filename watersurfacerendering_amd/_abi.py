@@ -34,7 +34,7 @@ SYMBOLS = [
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_frame_tracking", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
-    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_export_maps", "ocean_bind_output",
+    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_export_maps", "ocean_bind_output", "ocean_bind_output_dmabuf",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_comm_count", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
     "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
         "ocean_last_rccl_error": (i32, []),
         "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
         "ocean_bind_output": (i32, [P, P, P]),
+        "ocean_bind_output_dmabuf": (i32, [P, i32, C.c_size_t, C.c_size_t, C.c_size_t]),
         "ocean_export_maps": (i32, [P, C.POINTER(i32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32)]),
         "ocean_displace_grid": (i32, [P, u32, u32, f32, f32, f32]),
         "ocean_displace_grid_cascades": (i32, [P, u32, u32, u32, f32, FP, f32]),

@@ -30,6 +30,7 @@ static thread_local int g_last_hip = 0;
 
 static void free_set(ocean_ctx* c, int i);
 static void comm_release(ocean_ctx* c);
+static void release_import(ocean_ctx* c);
 
 static void free_device(ocean_ctx* c)
 {
@@ -234,6 +235,7 @@ void ocean_destroy(ocean_t* c)
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
     comm_release(c);
+    release_import(c);
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->grid_pos) (void)hipFree(c->grid_pos);
@@ -295,6 +297,7 @@ int ocean_set_tile_size(ocean_t* c, uint32_t tile_size)
     SYNC_ALL(c);
     free_device(c);
     c->n = tile_size;
+    release_import(c);
     c->ext_disp = nullptr; c->ext_nrm = nullptr;
     int rc = alloc_device(c);
     if (rc) return rc;
@@ -745,14 +748,47 @@ int ocean_export_maps(ocean_t* c, int* dmabuf_fd, size_t* disp_offset, size_t* n
     return OCEAN_OK;
 }
 
+static void release_import(ocean_ctx* c)
+{
+    if (c->import_mem) { (void)hipDestroyExternalMemory(c->import_mem); c->import_mem = nullptr; c->import_base = nullptr; }
+}
+
 int ocean_bind_output(ocean_t* c, void* d_disp, void* d_nrm)
 {
     if (!c) return OCEAN_E_INVALID;
     if (((uintptr_t)d_disp | (uintptr_t)d_nrm) & 15u) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
+    release_import(c);                  // a binding made by ocean_bind_output_dmabuf ends here
     c->ext_disp = (float4*)d_disp;
     c->ext_nrm = (float4*)d_nrm;
+    return OCEAN_OK;
+}
+
+int ocean_bind_output_dmabuf(ocean_t* c, int dmabuf_fd, size_t bytes, size_t disp_offset, size_t nrm_offset)
+{
+    if (!c || dmabuf_fd < 0) return OCEAN_E_INVALID;
+    const size_t map_bytes = (size_t)c->tiles * c->n * c->n * sizeof(float4);
+    if ((disp_offset | nrm_offset) & 15u) return OCEAN_E_INVALID;
+    if (disp_offset + map_bytes > bytes || nrm_offset + map_bytes > bytes) return OCEAN_E_INVALID;
+    if (disp_offset < nrm_offset + map_bytes && nrm_offset < disp_offset + map_bytes) return OCEAN_E_INVALID;      // the two maps overlap
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    hipExternalMemoryHandleDesc hd = {};
+    hd.type = hipExternalMemoryHandleTypeOpaqueFd;        // what amdgpu's dma-buf descriptors are imported as
+    hd.handle.fd = dmabuf_fd;
+    hd.size = bytes;
+    hipExternalMemory_t mem = nullptr;
+    HIP_TRY(hipImportExternalMemory(&mem, &hd));
+    hipExternalMemoryBufferDesc bd = {};
+    bd.offset = 0; bd.size = bytes;
+    void* base = nullptr;
+    hipError_t e = hipExternalMemoryGetMappedBuffer(&base, mem, &bd);
+    if (e != hipSuccess) { (void)hipDestroyExternalMemory(mem); g_last_hip = (int)e; return OCEAN_E_HIP; }
+    release_import(c);
+    c->import_mem = mem; c->import_base = base;
+    c->ext_disp = reinterpret_cast<float4*>(static_cast<char*>(base) + disp_offset);
+    c->ext_nrm = reinterpret_cast<float4*>(static_cast<char*>(base) + nrm_offset);
     return OCEAN_OK;
 }
 

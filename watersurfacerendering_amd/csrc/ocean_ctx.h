@@ -64,6 +64,8 @@ struct ocean_ctx {
     size_t maps_bytes[MAXD] = {};  // size of that allocation (a whole number of 2 MiB pages: ocean_export_maps)
     float4* ext_disp = nullptr;
     float4* ext_nrm = nullptr;
+    hipExternalMemory_t import_mem = nullptr;   // ocean_bind_output_dmabuf: the imported memory object ext_disp / ext_nrm point into
+    void* import_base = nullptr;
     float* toff = nullptr;
     bool use_toff = false;
     std::vector<float> toff_host;   // the per-tile time offsets as set by the caller (re-uploaded when the device buffers are re-created)
