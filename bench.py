@@ -597,11 +597,10 @@ def main():
     b.close()
     torch.cuda.empty_cache()
     # The serial pass runs in a context of its own at depth 1 -- what a caller of the synchronous ComputeWaves has -- and the
-    # serial frames of the bench context are reported beside it (roofline.serial_kernels_in_bench_context_us).  In three of
-    # about a dozen bench processes of round 2 serial k_xpass_b ran at 33 instead of 25.5 us at 2048^2, in both contexts of
-    # such a process and under rocprofv3 alike, while the same sequence in the next process on the same box ran at 25.5; a
-    # serial 2048^2 frame keeps spectrum + intermediates + plainly stored maps = 242 MB in the 256 MiB memory-side cache, which
-    # makes it sensitive to the state the device is in.  The cause was not found (tools/bimodal*.py are the probes).
+    # serial frames of the bench context are reported beside it (roofline.serial_kernels_in_bench_context_us): in rare
+    # processes serial k_xpass_b runs slower in ONE of a process's contexts for that context's whole life (24-28 instead of
+    # 21 us at 2048^2; 33 instead of 25.5 in round 2).  The cause was not found (profiles/r03_bimodal_probe.txt); with both
+    # contexts on the line a reader can tell such a run from a normal one.
     bs = W.OceanBatch(n, tiles, local_rank)
     bs.prepare(SEED + first_tile)
     ms_serial, kern_ms = bs.time_frames(0.0, DT, 300, nk, per_kernel=True)
