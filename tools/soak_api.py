@@ -1,6 +1,8 @@
 """Soak of the frame path's host side (round 3): thousands of randomly mixed operations -- synchronous calls (tracked: completion records),
-asynchronous frames with and without tracking, ocean_wait_frame, read-outs, mode / depth / lambda changes, resizes -- on one long-lived context,
-every returned amplitude and (sampled) map checked against a second context that only ever runs fully synchronised serial frames.
+asynchronous frames with and without tracking, ocean_wait_frame, read-outs (plain, asynchronous into registered memory, staging layout), mode /
+depth / lambda / parameter / dispersion / precision / time-offset changes, resizes, mip chains, the vertex-stage consumer, dma-buf exports -- on
+one long-lived context, every returned amplitude and (sampled) map checked against a second context that only ever runs fully synchronised
+serial frames and is re-created from scratch now and then (so that stale state in the long-lived one cannot hide in both).
 usage: soak_api.py [operations] [seed]"""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,11 +13,21 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 sizes = [64, 256, 512, 1024]
 n, tiles = 256, 2
 b = W.OceanBatch(n, tiles, 0); r = W.OceanBatch(n, tiles, 0)
-state = dict(mode=0, depth=1, lam=-1.0, seed=5)
+state = dict(mode=0, depth=1, lam=-1.0, seed=5, inter=32, spec=32, disp=(0, 0.0), wind=(20.0, 1.0, 0.5), length=1000.0, offs=None)
 def reprepare():
     for c in (b, r):
-        c.set_mode(state["mode"]); c.set_lambda(state["lam"]); c.prepare(state["seed"])
+        c.set_mode(state["mode"]); c.set_intermediate_precision(state["inter"]); c.set_spectrum_precision(state["spec"])
+        c.set_dispersion(*state["disp"])
+        c.set_params(wind_speed=state["wind"][0], wind_dir_x=state["wind"][1], wind_dir_y=state["wind"][2], tile_length=state["length"])
+        c.set_lambda(state["lam"]); c.set_time_offsets(state["offs"]); c.prepare(state["seed"])
     b.set_pipeline_depth(state["depth"])
+def fresh_reference():
+    """the reference context from scratch: whatever the long-lived one has been through, a new one must agree with it"""
+    global r
+    r.close(); r = W.OceanBatch(n, tiles, 0)
+    r.set_mode(state["mode"]); r.set_intermediate_precision(state["inter"]); r.set_spectrum_precision(state["spec"]); r.set_dispersion(*state["disp"])
+    r.set_params(wind_speed=state["wind"][0], wind_dir_x=state["wind"][1], wind_dir_y=state["wind"][2], tile_length=state["length"])
+    r.set_lambda(state["lam"]); r.set_time_offsets(state["offs"]); r.prepare(state["seed"])
 reprepare()
 last_t, checked, bad = None, 0, 0
 def ref(t):
@@ -48,6 +60,42 @@ for k in range(ops):
         state["seed"] = rng.randrange(1 << 30); reprepare(); last_t = None
     elif op < 0.93:
         n = rng.choice(sizes); b.set_tile_size(n); r.set_tile_size(n); reprepare(); last_t = None
+    elif op < 0.94:
+        what = rng.randrange(6)
+        if what == 0: state["inter"] = rng.choice([16, 32])
+        elif what == 1: state["spec"] = rng.choice([16, 32])
+        elif what == 2: state["disp"] = rng.choice([(0, 0.0), (1, 25.0), (2, 0.05)])
+        elif what == 3: state["wind"] = (rng.uniform(2.0, 40.0), rng.uniform(-1, 1), rng.uniform(0.1, 1))
+        elif what == 4: state["length"] = rng.choice([250.0, 1000.0, 3000.0])
+        else: state["offs"] = rng.choice([None, [0.25 * i for i in range(tiles)]])
+        reprepare(); last_t = None
+    elif op < 0.945:
+        fresh_reference()
+    elif op < 0.955 and last_t is not None:
+        tile = rng.randrange(tiles)
+        md, mq = b.build_mips(tile); ref(last_t); rd, rq = r.build_mips(tile)
+        bad += not all(np.array_equal(x, y) for x, y in zip(md + mq, rd + rq)); checked += 1
+    elif op < 0.965 and last_t is not None:
+        tile, g = rng.randrange(tiles), rng.choice([16, 64])
+        p1, q1 = b.displace_grid(tile, g, uv_scale=rng.choice([1.0, 0.37])); 
+        ref(last_t); p2, q2 = r.displace_grid(tile, g, uv_scale=1.0)
+        p3, q3 = b.displace_grid(tile, g, uv_scale=1.0)
+        bad += not (np.array_equal(p3, p2) and np.array_equal(q3, q2)); checked += 1
+    elif op < 0.975 and last_t is not None:
+        tile = rng.randrange(tiles)
+        vb, ib = rng.choice([(0, 0), (40, 12), (4096, 36)])
+        off = (vb + ib + 15) // 16 * 16
+        stag = np.zeros(off + 2 * n * n * 16, dtype=np.uint8)
+        used = b.read_maps_staging(stag, vb, ib, tile); b.synchronize()
+        ref(last_t); d2, q2 = r.read_maps(tile, 1)
+        bad += not (used == stag.size and stag[off:].tobytes() == d2.tobytes() + q2.tobytes()); checked += 1
+    elif op < 0.98 and last_t is not None:
+        d = np.empty((tiles, n, n, 4), np.float32); q = np.empty_like(d)
+        b.read_maps_async(d, q); b.synchronize()
+        ref(last_t); d2, q2 = r.read_maps()
+        bad += not (np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
+    elif op < 0.985 and last_t is not None and state["depth"] == 1:
+        fd = b.export_maps()[0]; os.close(fd)
     elif last_t is not None:
         h = [b.heights(i) for i in range(tiles)]
         ref(last_t)
