@@ -120,6 +120,47 @@ REFERENCE_METHODS = [  # /root/reference/src/scene/WSTessendorf.h:58-122
 ]
 
 
+def test_reference_method_list_is_the_reference_headers():
+    """Where the reference tree is present (the build container; never the GPU box) the list above is checked against the
+    public section of its header: every public method of WSTessendorf, none missing, none invented."""
+    hdr_path = "/root/reference/src/scene/WSTessendorf.h"
+    if not os.path.exists(hdr_path):
+        pytest.skip("reference tree not present")
+    text = open(hdr_path).read()
+    public = text[text.index("public:"):text.index("private:")]
+    public = re.sub(r"/\*.*?\*/", "", public, flags=re.S)
+    public = re.sub(r"//[^\n]*", "", public)
+    names = set(re.findall(r"\b((?:Get|Set)[A-Za-z]+|Prepare|ComputeWaves)\s*\(", public))
+    assert names == set(REFERENCE_METHODS), (sorted(names - set(REFERENCE_METHODS)), sorted(set(REFERENCE_METHODS) - names))
+
+
+def test_default_parameters_are_the_reference_headers(abi):
+    """ocean_default_params against the s_kDefault* constants and the m_Lambda initialiser parsed from the reference header
+    (build container only)."""
+    hdr_path = "/root/reference/src/scene/WSTessendorf.h"
+    if not os.path.exists(hdr_path):
+        pytest.skip("reference tree not present")
+    text = open(hdr_path).read()
+
+    def const(name):
+        m = re.search(r"\b%s\s*\{([^}]*)\}" % name, text)
+        assert m, name
+        return [float(x.strip().rstrip("f")) for x in m.group(1).split(",")]
+
+    p = abi.Params()
+    abi.lib().ocean_default_params(C.byref(p))
+    f32 = lambda x: C.c_float(x).value
+    assert [p.tile_length] == [f32(v) for v in const("s_kDefaultTileLength")]
+    assert [p.wind_dir_x, p.wind_dir_y] == [f32(v) for v in const("s_kDefaultWindDir")]
+    assert [p.wind_speed] == [f32(v) for v in const("s_kDefaultWindSpeed")]
+    assert [p.anim_period] == [f32(v) for v in const("s_kDefaultAnimPeriod")]
+    assert [p.phillips_const] == [f32(v) for v in const("s_kDefaultPhillipsConst")]
+    assert [p.damping] == [f32(v) for v in const("s_kDefaultPhillipsDamping")]
+    assert [p.lambda_] == [f32(v) for v in const("m_Lambda")]
+    import watersurfacerendering_amd as W
+    assert [float(W.WSTessendorf.s_kDefaultTileSize)] == const("s_kDefaultTileSize")
+
+
 def test_python_mirror_has_reference_surface():
     import watersurfacerendering_amd as W
     for m in REFERENCE_METHODS:
