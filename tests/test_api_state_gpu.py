@@ -298,3 +298,42 @@ def test_maps_written_into_memory_another_process_owns(tmp_path):
     assert L.ocean_bind_output_dmabuf(owner._h, 0, 16, 0, 0) == _abi.OCEAN_E_INVALID              # too small for the maps
     assert L.ocean_bind_output_dmabuf(owner._h, 0, nbytes, 0, 64) == _abi.OCEAN_E_INVALID         # overlapping maps
     owner.close()
+
+
+def test_dmabuf_binding_leaves_the_descriptor_with_the_caller():
+    """ocean_bind_output_dmabuf inside ONE process (an allocation of another context stands in for the renderer's), twice with the same
+    descriptor: the import holds its own reference, the caller's descriptor stays open and usable through import, re-binding, un-binding and
+    ocean_destroy (include/ocean.h says so; CUDA-style ownership transfer would make the caller's close() a double close)."""
+    import os
+    import watersurfacerendering_amd as W
+    n = 256
+    owner = W.OceanBatch(n, 1, 0)
+    owner.prepare(1)
+    owner.compute_waves(0.0)
+    fd, doff, noff, nbytes, _ = owner.export_maps()
+    ref = W.OceanBatch(n, 1, 0)
+    ref.prepare(SEED + 5)
+    try:
+        b = W.OceanBatch(n, 1, 0)
+        b.prepare(SEED + 5)
+        for t in (1.0, 2.0):
+            b.bind_output_dmabuf(fd, nbytes, doff, noff)
+            os.fstat(fd)                                   # still the caller's
+            amp = b.compute_waves(t)
+            b.synchronize()
+            amp_ref = ref.compute_waves(t)
+            d, q = owner.read_maps()
+            d2, q2 = ref.read_maps()
+            assert np.array_equal(amp, amp_ref) and np.array_equal(d, d2) and np.array_equal(q, q2)
+            b.bind_output(None, None)                      # ends the binding; the next frame goes to the context's own maps
+            os.fstat(fd)
+        b.compute_waves(3.0)
+        d3, _ = b.read_maps()
+        ref.compute_waves(3.0)
+        assert np.array_equal(d3, ref.read_maps()[0]) and np.array_equal(owner.read_maps()[0], d)    # and no longer to the owner's
+        b.bind_output_dmabuf(fd, nbytes, doff, noff)
+        b.close()                                          # destroy with a live binding
+        os.fstat(fd)
+    finally:
+        os.close(fd)
+    owner.close(); ref.close()
