@@ -337,3 +337,32 @@ def test_dmabuf_binding_leaves_the_descriptor_with_the_caller():
     finally:
         os.close(fd)
     owner.close(); ref.close()
+
+
+def test_out_of_memory_is_reported_as_such_and_leaves_the_device_usable():
+    """A context that cannot fit (60 000 tiles of 4096^2: 8 TB of spectrum alone) is refused with OCEAN_E_NOMEM -- not a generic HIP error, no
+    handle, nothing left allocated -- and the next context works and delivers the usual frame (the failed allocation's sticky HIP error is cleared)."""
+    import ctypes as C
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi
+    L = _abi.lib()
+    ref = W.OceanBatch(256, 1, 0)
+    ref.prepare(SEED)
+    a0 = ref.compute_waves(1.0)
+    d0, q0 = ref.read_maps()
+    h = C.c_void_p()
+    assert L.ocean_create(C.byref(h), 4096, 60000, 0) == _abi.OCEAN_E_NOMEM
+    assert not h.value
+    b = W.OceanBatch(256, 1, 0)
+    b.prepare(SEED)
+    a1 = b.compute_waves(1.0)
+    d1, q1 = b.read_maps()
+    assert np.array_equal(a0, a1) and np.array_equal(d0, d1) and np.array_equal(q0, q1)
+    # a resize that cannot fit: refused the same way, and the context recovers with a size that fits
+    big = W.OceanBatch(64, 40000, 0)
+    assert L.ocean_set_tile_size(big._h, 4096) == _abi.OCEAN_E_NOMEM
+    assert L.ocean_compute_waves_async(big._h, 0.0) == _abi.OCEAN_E_NOT_READY
+    big.set_tile_size(16)
+    big.prepare(SEED)
+    big.compute_waves(0.5)
+    big.close(); b.close(); ref.close()

@@ -24,7 +24,8 @@ static thread_local int g_last_hip = 0;
         hipError_t e_ = (expr);                         \
         if (e_ != hipSuccess) {                         \
             g_last_hip = (int)e_;                       \
-            return OCEAN_E_HIP;                         \
+            (void)hipGetLastError();                    \
+            return e_ == hipErrorOutOfMemory ? OCEAN_E_NOMEM : OCEAN_E_HIP; \
         }                                               \
     } while (0)
 
