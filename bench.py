@@ -287,6 +287,20 @@ def measure_sync_calls(W, n, device, calls=300):
             "what": "host-side wall time of ocean_compute_waves (enqueue + the frame + one stream synchronisation; min/max keys arrive in host-coherent memory), called from Python"}
 
 
+def measure_stream_selection(W, n, device):
+    """ocean_select_streams: serial frames before, the four candidate queues, serial frames after (a context of its own)."""
+    b = W.OceanBatch(n, 1, device)
+    b.prepare(SEED)
+    ms0, _ = b.time_frames(0.0, DT, 300, 500, per_kernel=False)
+    cand = b.select_streams(50)
+    ms1, _ = b.time_frames(0.0, DT, 300, 500, per_kernel=False)
+    b.close()
+    return {"size": n, "serial_us_per_frame_before": ms0 / 500 * 1e3, "candidate_queues_us_per_frame": cand,
+            "serial_us_per_frame_after": ms1 / 500 * 1e3,
+            "what": "opt-in ocean_select_streams(50): serial frames timed on each of the context's first four streams (one per hardware queue of "
+                    "the process), streams re-ordered fastest first; the headline and every other figure of this line do NOT use it"}
+
+
 def measure_consumer(W, n, device, calls=200):
     """Vertex-stage consumer: (n+1)^2 displaced vertices + normals from the maps of one frame."""
     b = W.OceanBatch(n, 1, device)
@@ -665,6 +679,7 @@ def main():
             extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 2000, 500, mode=2)
             extra["512x512_synchronous_calls"] = measure_sync_calls(W, 512, local_rank)
             extra["2048x2048_synchronous_calls"] = measure_sync_calls(W, 2048, local_rank)
+            extra["2048x2048_stream_selection"] = measure_stream_selection(W, 2048, local_rank)
             extra["vertex_stage_512"] = measure_consumer(W, 512, local_rank)
             extra["vertex_stage_2048"] = measure_consumer(W, 2048, local_rank)
             extra["512x512_batch16"] = measure_config(W, 512, 16, local_rank, 1000, 300)

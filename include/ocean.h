@@ -337,6 +337,17 @@ int ocean_gather_maps_f16(ocean_t* ctx, int root, void* d_recv_disp, void* d_rec
 /* ncclResult_t of the most recent failing RCCL call on this thread (0 if none).                 */
 int ocean_last_rccl_error(void);
 
+/* Optional, once after ocean_prepare: put the context's work on the fastest of the process's hardware queues.  HIP spreads a process's
+ * streams over four hardware queues, and on MI355X these are not alike: every kernel of a frame differs by up to 1 us between them, and
+ * about one process in 4...25 is handed a queue on which the normal-map pass alone takes 1.5-3.5 us longer (DESIGN.md section 6,
+ * profiles/r03_bimodal_probe.txt).  The call times `frames` serial frames (plus five untimed ones) on each of the context's first four
+ * streams -- one per queue -- and re-orders its streams, fastest first: the serial path (the synchronous ocean_compute_waves) and pipeline
+ * chain 0 then use the fastest queue, chains 1..3 the next ones.  us_per_frame (NULL or 4 floats) receives the measured frame times in
+ * the new order.  50 frames tell the queues apart (4 x 55 frames: 14 ms at 2048^2, 4 ms at 512^2).  Afterwards the maps hold a calibration
+ * frame (read-outs return OCEAN_E_NOT_READY until the next frame), and a stream handle fetched earlier with ocean_stream() may no longer be
+ * the context's.  OCEAN_E_UNSUPPORTED with a caller-owned stream (ocean_set_stream).  Results of frames are unaffected: bit-identical. */
+int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [4] or NULL */);
+
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */
 int ocean_read_spectrum(ocean_t* ctx, uint32_t tile, float* h0, float* omega);

@@ -366,3 +366,45 @@ def test_out_of_memory_is_reported_as_such_and_leaves_the_device_usable():
     big.prepare(SEED)
     big.compute_waves(0.5)
     big.close(); b.close(); ref.close()
+
+
+def test_stream_selection_orders_the_queues_and_changes_no_bit():
+    """ocean_select_streams: four frame times, fastest first; frames before and after the re-ordering -- serial, pipelined at depth 3, tracked,
+    read out -- are the frames of an untouched context bit for bit; the calibration frame is not handed out as a result."""
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi
+    n = 1024
+    ref = W.OceanBatch(n, 1, 0)
+    ref.prepare(SEED + 3)
+    b = W.OceanBatch(n, 1, 0)
+    assert _abi.lib().ocean_select_streams(b._h, 10, None) == _abi.OCEAN_E_NOT_READY        # before ocean_prepare
+    b.prepare(SEED + 3)
+    a0 = b.compute_waves(0.5)
+    us = b.select_streams(30)
+    assert len(us) == 4 and all(u > 0 for u in us) and us == sorted(us)
+    assert max(us) < 3 * min(us)                                  # four queues of one device: the same order of magnitude
+    with pytest.raises(_abi.OceanError):                          # the calibration frame is not a result
+        b.read_maps()
+    assert np.array_equal(a0, ref.compute_waves(0.5))
+    for t in (0.5, 1.75):
+        a = b.compute_waves(t)
+        d, q = b.read_maps()
+        ar = ref.compute_waves(t)
+        dr, qr = ref.read_maps()
+        assert np.array_equal(a, ar) and np.array_equal(d, dr) and np.array_equal(q, qr)
+    b.set_pipeline_depth(3)
+    b.set_frame_tracking(True)
+    for j in range(7):
+        b.compute_waves_async(0.3 * j)
+    a = b.wait_frame()
+    b.synchronize()
+    d, q = b.read_maps()
+    ar = ref.compute_waves(0.3 * 6)
+    dr, qr = ref.read_maps()
+    assert np.array_equal(a, ar) and np.array_equal(d, dr) and np.array_equal(q, qr)
+    us2 = b.select_streams(30)                                    # again, at depth 3: still serial calibration frames, same contract
+    assert us2 == sorted(us2)
+    b.compute_waves_async(2.5); b.synchronize()
+    ref.compute_waves(2.5)
+    assert np.array_equal(b.read_maps()[0], ref.read_maps()[0])
+    b.close(); ref.close()

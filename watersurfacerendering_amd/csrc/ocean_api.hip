@@ -4,6 +4,7 @@
 // file: without a usable device every entry point returns an error.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1046,6 +1047,49 @@ int ocean_set_pipeline_depth(ocean_t* c, int depth)
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
     c->depth = depth;
+    return OCEAN_OK;
+}
+
+int ocean_select_streams(ocean_t* c, uint32_t frames, float* us_per_frame)
+{
+    // The context's eight streams sit on the process's four hardware queues in turn, and the queues are not alike: every kernel differs by up to
+    // 1 us between them, and about one process in 4...25 is handed a queue on which k_xpass_b takes 1.5-3.5 us longer (profiles/r03_bimodal_probe.txt).
+    // Nothing tells a stream's queue but timing: serial frames on the first four streams (one per queue), then the streams are re-ordered,
+    // fastest first -- the serial path and chain 0 use the fastest queue, chains 1..3 the next ones.  The maps hold a calibration frame afterwards.
+    if (!c || frames == 0) return OCEAN_E_INVALID;
+    if (!c->prepared) return OCEAN_E_NOT_READY;
+    if (c->user) return OCEAN_E_UNSUPPORTED;               // a caller-owned stream: nothing to choose
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    constexpr int CAND = 4;
+    float us[CAND];
+    int rc;
+    for (int k = 0; k < CAND; ++k) {
+        std::swap(c->own[0], c->own[k]);                   // candidate k runs the serial path (chain 0's buffers)
+        rc = OCEAN_OK;
+        for (int j = 0; j < 5 && !rc; ++j) rc = enqueue_frame(c, 0.25f * (float)j, false, nullptr);
+        hipError_t e = rc ? hipSuccess : hipStreamSynchronize(c->own[0]);
+        if (!rc && e == hipSuccess) e = hipEventRecord(c->start_ev, c->own[0]);
+        for (uint32_t j = 0; j < frames && !rc && e == hipSuccess; ++j) rc = enqueue_frame(c, 0.25f * (float)j, false, nullptr);
+        if (!rc && e == hipSuccess) e = hipEventRecord(c->end_ev[0], c->own[0]);
+        if (!rc && e == hipSuccess) e = hipEventSynchronize(c->end_ev[0]);
+        float ms = 0.f;
+        if (!rc && e == hipSuccess) e = hipEventElapsedTime(&ms, c->start_ev, c->end_ev[0]);
+        std::swap(c->own[0], c->own[k]);
+        if (rc) return rc;
+        if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
+        us[k] = ms * 1000.0f / (float)frames;
+    }
+    int order[CAND] = {0, 1, 2, 3};
+    std::sort(order, order + CAND, [&](int a, int b) { return us[a] < us[b]; });
+    hipStream_t sorted[CAND];
+    for (int k = 0; k < CAND; ++k) sorted[k] = c->own[order[k]];
+    for (int k = 0; k < CAND; ++k) {
+        c->own[k] = sorted[k];
+        if (us_per_frame) us_per_frame[k] = us[order[k]];
+    }
+    c->have_frame = false;                                 // the maps hold a calibration frame: nothing to read out until the next frame
+    c->last_set = 0;
     return OCEAN_OK;
 }
 
