@@ -96,6 +96,8 @@ for k in range(ops):
         bad += not (np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
     elif op < 0.985 and last_t is not None and state["depth"] == 1:
         fd = b.export_maps()[0]; os.close(fd)
+    elif op < 0.99:
+        b.select_streams(3); last_t = None          # streams re-ordered; the maps hold a calibration frame
     elif last_t is not None:
         h = [b.heights(i) for i in range(tiles)]
         ref(last_t)
