@@ -152,6 +152,14 @@ public:
     }
     bool Pending() const { return m_Pending; }
 
+    // Opt-in, once after Prepare(): put the model's work on the fastest of the process's hardware queues (ocean_select_streams: the queues
+    // of an MI355X process differ by up to 1 us per kernel).  Costs 4 x 55 frames; the next ComputeWaves delivers as ever.
+    void SelectFastestQueue(uint32_t framesPerQueue = 50)
+    {
+        Wait();
+        Check(ocean_select_streams(m_Ctx, framesPerQueue, nullptr), "ocean_select_streams");
+    }
+
     // Getters: WSTessendorf.h:82-107
     auto GetTileSize() const { return ocean_tile_size(m_Ctx); }
     auto GetTileLength() const { return m_Params.tile_length; }

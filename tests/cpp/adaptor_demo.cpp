@@ -21,6 +21,7 @@ int main(int argc, char** argv)
         model.SetWindSpeed(20.0f);
         model.SetLambda(-1.5f);
         model.Prepare(42);
+        if (argc > 5 && std::strcmp(argv[5], "select") == 0) model.SelectFastestQueue(20);   // must not change a bit of what follows
         const float amp = model.ComputeWaves(t);
 
         const size_t dispBytes = sizeof(WSTessendorf::Displacement) * model.GetDisplacementCount();

@@ -371,6 +371,9 @@ def test_cpp_adaptor_matches_python_binding(tmp_path):
     n, amp, mn, mx, sd, sn = first.split()
     tag, ok, us_amp, us_maps = second.split()       # ComputeWavesAsync() / Wait(): same frame as the blocking call, front pair untouched meanwhile
     assert tag == "async" and ok == "1", second
+    # the same with the opt-in SelectFastestQueue() ahead of the first frame: not a character of the output may change
+    r2 = subprocess.run([str(exe), "128", "1.5", "0", "noasync", "select"], capture_output=True, text=True, check=True)
+    assert r2.stdout.strip().splitlines()[0] == first
     b = make_gpu(128, None, seed=42, wind=(1.0, 0.5), wind_speed=20.0, lam=-1.5)
     a = float(b.compute_waves(1.5)[0])
     d, q = b.read_maps()

@@ -392,6 +392,11 @@ class WSTessendorf:
 
     # -- opt-in non-blocking pair (include/WSTessendorf.hpp: ComputeWavesAsync / Wait; the reference's DOUBLE_BUFFERED idea,
     #    WaterSurfaceMesh.h:26-34, on the synthesis side) ---------------------------------------------------------------------
+    def SelectFastestQueue(self, framesPerQueue: int = 50):
+        """Opt-in, once after Prepare(): the model's work on the fastest hardware queue of the process (include/WSTessendorf.hpp)."""
+        self.Wait()
+        return self._b.select_streams(framesPerQueue)
+
     def ComputeWavesAsync(self, time: float) -> float:
         """Enqueue the frame and the DMA of both maps into a back pair of pinned arrays; return A as soon as the frame's kernels
         are done (ocean_wait_frame).  GetDisplacements() / GetNormals() keep returning the previous frame until Wait()."""
