@@ -1162,6 +1162,21 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
     return OCEAN_OK;
 }
 
+#ifdef OCEAN_XB_TRACE
+// diagnostic build only (tools/xb_trace.py): enable = allocate the trace buffer (the next frames' k_xpass_b fill it); host_out = copy it out
+extern "C" int ocean_debug_xb_trace(ocean_t* c, int enable, unsigned long long* host_out, size_t count)
+{
+    if (!c) return OCEAN_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    if (enable && !c->stamps) {
+        HIP_TRY(hipMalloc(&c->stamps, (size_t)1 << 20));
+        HIP_TRY(hipMemset(c->stamps, 0, (size_t)1 << 20));
+    }
+    if (host_out) HIP_TRY(hipMemcpy(host_out, c->stamps, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+#endif
 #ifdef OCEAN_STAMPS
 // diagnostic build only: per-workgroup clock stamps of the last frame
 int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, size_t count)

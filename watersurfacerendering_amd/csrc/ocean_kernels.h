@@ -1038,6 +1038,26 @@ __device__ __forceinline__ void for_each_output(int tid, F f)
 // one height launch, then all three pairs per workgroup with register prefetch -- was
 // measured slower at every size and removed.)
 // ============================================================================
+#ifdef OCEAN_XB_TRACE
+// diagnostic build only (tools/xb_trace.py, profiles/r03_xpass_trace.txt): per workgroup of the two x passes, where and when it ran --
+// [record][4] = {start, end (100 MHz wall clock), HW_REG_HW_ID, HW_REG_XCC_ID}; records 0.. = k_xpass_b's workgroups, 512.. = k_xpass_disp's
+static __device__ unsigned long long* g_xb_trace = nullptr;
+struct XbTrace {
+    unsigned long long* p;
+    __device__ explicit XbTrace(unsigned base = 0) : p(nullptr)
+    {
+        if (threadIdx.x == 0 && g_xb_trace && blockIdx.y == 0) {
+            p = g_xb_trace + 4 * (size_t)(base + blockIdx.x);
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p[2] = hwid; p[3] = xcc;
+            p[0] = wall_clock64();
+        }
+    }
+    __device__ ~XbTrace() { if (p) p[1] = wall_clock64(); }       // thread 0 leaves the kernel: its last store has been issued (not drained)
+};
+#endif
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 {
@@ -1046,6 +1066,9 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
+#ifdef OCEAN_XB_TRACE
+    XbTrace xb_trace_;
+#endif
     constexpr int LM = 1;                                 // last-stage lane layout (fft_engine.h): a wave = one map row, 1 KiB bursts
     TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
@@ -1268,6 +1291,9 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
+#ifdef OCEAN_XB_TRACE
+    XbTrace xd_trace_(512);
+#endif
     constexpr int NB = (HF::NU + C - 1) / C;
     const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
     const float2* __restrict__ z0 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + (size_t)tile * HF::Z_TILE * (Z16 ? 4 : 8));

@@ -145,6 +145,12 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #define OCEAN_XPASS(kern, grid, lds, ev, nts)                                                                       \
         do { if (stream_maps & 8) OCEAN_XPASS2(kern, grid, lds, ev, nts, true);                                       \
              else OCEAN_XPASS2(kern, grid, lds, ev, nts, false); } while (0)
+#ifdef OCEAN_XB_TRACE
+        {   // diagnostic: this translation unit's copy of the trace pointer, set when the context's buffer changes (not per frame)
+            static unsigned long long* armed = nullptr;
+            if (armed != c->stamps) { armed = c->stamps; (void)hipMemcpyToSymbol(HIP_SYMBOL(ocean::g_xb_trace), &armed, sizeof(armed)); }
+        }
+#endif
         if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true);
         else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false);
 #ifdef OCEAN_STAMPS
