@@ -611,10 +611,9 @@ def main():
     b.close()
     torch.cuda.empty_cache()
     # The serial pass runs in a context of its own at depth 1 -- what a caller of the synchronous ComputeWaves has -- and the
-    # serial frames of the bench context are reported beside it (roofline.serial_kernels_in_bench_context_us).  Two things move
-    # these figures between passes (profiles/r03_bimodal_probe.txt): the hardware queue a context's stream lands on (+-1 us per
-    # kernel, deterministic), and, in about one process in 4...25, a hardware queue on which serial k_xpass_b alone runs at
-    # 22.5-28 instead of 21 us at 2048^2 (what such a queue does differently was not found); with both passes on the line a reader can tell such a run from a normal one.
+    # serial frames of the bench context are reported beside it (roofline.serial_kernels_in_bench_context_us).  The hardware queue a
+    # context's stream lands on moves these figures by +-1 us per kernel between passes (profiles/r03_bimodal_probe.txt 4a); the slow
+    # k_xpass_b of earlier rounds (one process in 4...25) is gone since its victim workgroup is dispatched first (profiles/r03_xpass_trace.txt).
     bs = W.OceanBatch(n, tiles, local_rank)
     bs.prepare(SEED + first_tile)
     ms_serial, kern_ms = bs.time_frames(0.0, DT, 300, nk, per_kernel=True)

@@ -1172,7 +1172,15 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     // (writing the two halves of a texel separately -- 8-byte stores, no registers held
     // between the transforms -- was measured 50% slower: the partial lines do not meet in L2)
     using LS = LastStage<N, C, T, P, LM>;
-    const int u0 = xcd_swizzle(blockIdx.x - HB, NB) * C;
+    // Row groups: NB - 1 full ones (C map rows each, XCD-swizzled among themselves) and the group of row N/2 with C - 1 padding rows, which goes
+    // to the FIRST NORMAL workgroup.  Where the plain swizzle put it (block 385 of 387 at 2048^2) it ran as the younger of two workgroups on
+    // a CU, and on some hardware queues that one workgroup took 18-23 instead of 13 us and the kernel 22.5-30 instead of 21 us (per-workgroup
+    // trace, profiles/r03_xpass_trace.txt); dispatched first it has its CU's issue slots to itself (0 slow processes in 50 against 1 in 5 on the
+    // same box, interleaved) and costs nothing anywhere else.
+    // (From 2048 up, where a tile's workgroups outnumber the CUs; at 512^2 and 1024^2 -- every workgroup alone on a CU -- the plain swizzle is
+    // 0.3-0.5 us faster and stays.)
+    const int nid = (int)blockIdx.x - HB;
+    const int u0 = (N >= 2048 ? (nid == 0 ? NB - 1 : xcd_swizzle(nid - 1, NB - 1)) : xcd_swizzle(nid, NB)) * C;
     constexpr size_t ESN = Z16 ? 4 : 8;
     const float2* __restrict__ z1 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + ((size_t)tile * HF::Z_TILE + HF::Z_GROUP) * ESN);
     const float2* __restrict__ z2 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(z1) + HF::Z_GROUP * ESN);
