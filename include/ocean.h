@@ -338,9 +338,9 @@ int ocean_gather_maps_f16(ocean_t* ctx, int root, void* d_recv_disp, void* d_rec
 int ocean_last_rccl_error(void);
 
 /* Optional, once after ocean_prepare: put the context's work on the fastest of the process's hardware queues.  HIP spreads a process's
- * streams over four hardware queues, and on MI355X these are not alike: every kernel of a frame differs by up to 1 us between them, and
- * about one process in 4...25 is handed a queue on which the normal-map pass alone takes 1.5-3.5 us longer (DESIGN.md section 6,
- * profiles/r03_bimodal_probe.txt).  The call times `frames` serial frames (plus five untimed ones) on each of the context's first four
+ * streams over four hardware queues, and on MI355X these are not alike: every kernel of a frame differs by up to 1 us between them
+ * (profiles/r03_bimodal_probe.txt; the occasional queue on which the normal-map pass took 1.5-3.5 us longer no longer
+ * finds its victim: profiles/r03_xpass_trace.txt).  The call times `frames` serial frames (plus five untimed ones) on each of the context's first four
  * streams -- one per queue -- and re-orders its streams, fastest first: the serial path (the synchronous ocean_compute_waves) and pipeline
  * chain 0 then use the fastest queue, chains 1..3 the next ones.  us_per_frame (NULL or 4 floats) receives the measured frame times in
  * the new order.  50 frames tell the queues apart (4 x 55 frames: 14 ms at 2048^2, 4 ms at 512^2).  Afterwards the maps hold a calibration

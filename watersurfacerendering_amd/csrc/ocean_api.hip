@@ -1053,7 +1053,7 @@ int ocean_set_pipeline_depth(ocean_t* c, int depth)
 int ocean_select_streams(ocean_t* c, uint32_t frames, float* us_per_frame)
 {
     // The context's eight streams sit on the process's four hardware queues in turn, and the queues are not alike: every kernel differs by up to
-    // 1 us between them, and about one process in 4...25 is handed a queue on which k_xpass_b takes 1.5-3.5 us longer (profiles/r03_bimodal_probe.txt).
+    // 1 us between them (profiles/r03_bimodal_probe.txt section 4a).
     // Nothing tells a stream's queue but timing: serial frames on the first four streams (one per queue), then the streams are re-ordered,
     // fastest first -- the serial path and chain 0 use the fastest queue, chains 1..3 the next ones.  The maps hold a calibration frame afterwards.
     if (!c || frames == 0) return OCEAN_E_INVALID;
