@@ -1,20 +1,17 @@
 """Fresh processes, libraries interleaved: how many run serial k_xpass_b slow (> 22.4 us at 2048^2)?  (profiles/r03_bimodal_probe.txt)
-usage: xb_hunt.py <processes> <lib,lib,...> [stream]     lib = default or the NAME of watersurfacerendering_amd/libocean_hip_NAME.so;
-'stream': every process creates one torch stream ahead of the context (tools/xb_torch.py stream_before)"""
+usage: xb_hunt.py <processes> <lib,lib,...>     lib = default or the NAME of watersurfacerendering_amd/libocean_hip_NAME.so"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n, libs = int(sys.argv[1]), sys.argv[2].split(",")
-stream = len(sys.argv) > 3 and sys.argv[3] == "stream"
 slow = {L: [] for L in libs}; times = {L: [] for L in libs}
 for p in range(n):
     for L in libs:
         env = dict(os.environ)
         env.pop("OCEAN_HIP_LIB", None)
         if L != "default": env["OCEAN_HIP_LIB"] = os.path.join(root, "watersurfacerendering_amd", f"libocean_hip_{L}.so")
-        cmd = [sys.executable, os.path.join(root, "tools", "xb_torch.py"), "stream_before"] if stream else \
-              [sys.executable, os.path.join(root, "tools", "kernel_times.py"), "2048", "1", "200"]
+        cmd = [sys.executable, os.path.join(root, "tools", "kernel_times.py"), "2048", "1", "200"]
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root).stdout
-        m = re.search(r"k_xpass_b\s+([0-9.]+)", out) or re.search(r"z/xb/disp:\s+[0-9.]+/([0-9.]+)/", out)
+        m = re.search(r"k_xpass_b\s+([0-9.]+)", out)
         if not m:
             print(f"[{L}] process {p}: no timing in output: {out[-200:]!r}"); continue
         xb = float(m.group(1)); times[L].append(xb)
