@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define OCEAN_ABI_VERSION 3   /* 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
-                                 ocean_last_launch, ocean_export_maps (additions only) */
+                                 ocean_set_frame_tracking, ocean_last_launch, ocean_export_maps, ocean_bind_output_dmabuf, ocean_select_streams,
+                                 ocean_comm_count, ocean_algorithmic_bytes_per_launch (additions only) */
 
 enum {
     OCEAN_OK            =  0,
@@ -99,9 +100,13 @@ uint32_t ocean_tiles(const ocean_t* ctx);
 int ocean_prepare(ocean_t* ctx, uint64_t seed, const float* xi_or_null);
 
 /* ---- ComputeWaves(t): WSTessendorf.cpp:284-455.
- *      ocean_compute_waves        : synchronous; writes the height amplitude A
- *                                   of every tile to out_amp[tiles] (may be NULL)
- *                                   -- the reference's return value.
+ *      ocean_compute_waves        : synchronous in the reference's sense: when it
+ *                                   returns the frame's work is done and every
+ *                                   read-out call of this header sees it; writes
+ *                                   the height amplitude A of every tile to
+ *                                   out_amp[tiles] (may be NULL) -- the reference's
+ *                                   return value.  See ocean_wait_frame for what a
+ *                                   reader OUTSIDE the context's streams may assume.
  *      ocean_compute_waves_async  : enqueues the frame on the context's stream
  *                                   and returns; results are valid after
  *                                   ocean_synchronize (or stream order).
@@ -114,8 +119,13 @@ int ocean_compute_waves_async(ocean_t* ctx, float t);
  * Behind ocean_compute_waves (and behind asynchronous frames after ocean_set_frame_tracking) the wait is a short poll of
  * completion records the frame's last workgroup leaves in host-coherent memory -- no stream synchronisation, whose wake-up
  * costs 13-16 us per call at the reference's call shape, WaterSurfaceMesh.cpp:145-154; after 2 ms of polling it falls back
- * to hipStreamSynchronize.  When it returns, every workgroup of the frame has finished;
- * whatever then reads the maps is ordered by the stream as always (read-out calls, ocean_stream, ocean_synchronize).
+ * to hipStreamSynchronize.  When it returns, every workgroup of the frame has finished its work; a completion record is NOT a
+ * memory fence, so whatever then reads the maps must be ordered by the stream: the read-out calls of this header and work
+ * enqueued on ocean_stream() are.  A reader the stream does not order -- another stream, another API, another process -- needs
+ * ocean_synchronize() (or an event / semaphore of its own behind the frame).  For the cases the library can see, it does that
+ * itself: with caller-bound or imported output (ocean_bind_output, ocean_bind_output_dmabuf), after ocean_export_maps and after
+ * ocean_device_maps, ocean_wait_frame and ocean_compute_waves ARE a stream synchronisation (end-of-kernel release and cache
+ * write-back included) -- the fast poll is kept for contexts whose maps nobody else can see.
  * With ocean_read_maps_async / ocean_read_maps_staging enqueued BEFORE the wait, the caller gets A while the DMA of the
  * maps is still in flight: the reference's DOUBLE_BUFFERED idea (WaterSurfaceMesh.h:26-34) on the synthesis side;
  * include/WSTessendorf.hpp: ComputeWavesAsync() / Wait().                                                                */
@@ -128,8 +138,9 @@ int ocean_set_frame_tracking(ocean_t* ctx, int on);
 int ocean_set_time_offsets(ocean_t* ctx, const float* offsets_or_null /* tiles */);
 int ocean_synchronize(ocean_t* ctx);
 
-/* A, min, max of the last completed frame (GetMinHeight/GetMaxHeight,
- * WSTessendorf.h:91-92; A = ComputeWaves' return).  Synchronises.               */
+/* A, min, max of the most recently enqueued frame (GetMinHeight/GetMaxHeight,
+ * WSTessendorf.h:91-92; A = ComputeWaves' return).  Waits for that frame
+ * (like ocean_wait_frame), not for the other pipeline chains.                    */
 int ocean_get_heights(ocean_t* ctx, uint32_t tile, float* amp, float* min_h, float* max_h);
 
 /* ---- read-out: replaces GetDisplacements()/GetNormals() + the two memcpy's
@@ -170,7 +181,10 @@ int ocean_read_maps_staging(ocean_t* ctx, uint32_t tile, void* mapped_base, size
                             size_t indices_bytes, size_t* bytes_to_flush);
 
 /* Device pointers of the maps of tile 0 (tile i at +i*N*N*4 floats): zero-copy
- * hand-off to a device-side consumer (interop, RCCL gather).                     */
+ * hand-off to a device-side consumer (interop, RCCL gather).  A consumer on
+ * ocean_stream() is ordered by the stream; any other one orders itself with
+ * ocean_synchronize / ocean_wait_frame / ocean_compute_waves, which -- from this
+ * call on, until the maps are re-allocated -- synchronise the stream.            */
 int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
 
 /* Export of the maps as a dma-buf (the remainder: the reference uploads both maps every frame through a
@@ -189,14 +203,18 @@ int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
  *   *map_set     which of the context's map sets this is: the one of the most recently enqueued frame (set 0 before any
  *                frame).  At pipeline depth 1 there is only set 0 and one export serves every frame; at depth D frames
  *                rotate over D sets -- export after each of the first D frames, or keep depth 1 for an importing renderer.
- * Consumers order themselves with the frames as always: ocean_synchronize / ocean_wait_frame on the host, or an exported
- * semaphore of their own API.  Caller-bound output (ocean_bind_output) is not exported: OCEAN_E_UNSUPPORTED.            */
+ * Ordering for the importer: ocean_synchronize, ocean_wait_frame or the synchronous ocean_compute_waves on the host (once a map
+ * set has been exported the latter two synchronise the frame's stream instead of polling its completion records, so that the
+ * maps are written back and visible when they return), or a semaphore of the importer's own API.  Caller-bound output
+ * (ocean_bind_output) is not exported: OCEAN_E_UNSUPPORTED.                                                              */
 int ocean_export_maps(ocean_t* ctx, int* dmabuf_fd, size_t* disp_offset, size_t* nrm_offset, size_t* bytes, int* map_set);
 
 /* Make the context write its maps into caller-owned device memory
  * (tiles*N*N*4 floats each, 16-byte aligned), e.g. tensors owned by the
  * harness so a collective can send them without a copy.  NULL restores the
- * internal buffers.                                                              */
+ * internal buffers.  While output is bound, ocean_wait_frame and
+ * ocean_compute_waves synchronise the stream (the owner of the memory may read
+ * it on any stream or API when they return).                                     */
 int ocean_bind_output(ocean_t* ctx, void* d_disp, void* d_nrm);
 /* The other direction of ocean_export_maps: the RENDERER owns the memory.  It exports a VkDeviceMemory (or any device allocation) as a
  * dma-buf / opaque fd (vkGetMemoryFdKHR), and the context imports it (hipImportExternalMemory) and writes its maps straight into it at
@@ -247,9 +265,10 @@ int ocean_set_intermediate_precision(ocean_t* ctx, int bits);
 /* Frame pipelining.  With depth D consecutive asynchronous frames rotate over D
  * independent chains (own stream, own intermediates, own internal map set): the
  * first pass of one frame fills the memory-idle phases of the other frames' map
- * passes.  ocean_compute_waves waits for its own frame only; ocean_synchronize and the
- * read-out calls drain every chain; the read-out functions and ocean_device_maps then
- * refer to the frame enqueued last.  Caller-bound
+ * passes.  ocean_compute_waves, ocean_wait_frame and ocean_get_heights wait for the
+ * most recently enqueued frame only; ocean_synchronize and the map read-out calls drain
+ * every chain; the read-out functions and ocean_device_maps then refer to the frame
+ * enqueued last.  Caller-bound
  * output buffers (ocean_bind_output) or a caller stream force depth 1.  depth 1 (the
  * default) = everything on one stream.  (The reference is strictly serial; its own
  * DOUBLE_BUFFERED switch, WaterSurfaceMesh.h:34, is the same idea on the upload side.)  */
@@ -345,7 +364,8 @@ int ocean_last_rccl_error(void);
  * chain 0 then use the fastest queue, chains 1..3 the next ones.  us_per_frame (NULL or 4 floats) receives the measured frame times in
  * the new order.  50 frames tell the queues apart (4 x 55 frames: 14 ms at 2048^2, 4 ms at 512^2).  Afterwards the maps hold a calibration
  * frame (read-outs return OCEAN_E_NOT_READY until the next frame), and a stream handle fetched earlier with ocean_stream() may no longer be
- * the context's.  OCEAN_E_UNSUPPORTED with a caller-owned stream (ocean_set_stream).  Results of frames are unaffected: bit-identical. */
+ * the context's.  OCEAN_E_UNSUPPORTED with a caller-owned stream (ocean_set_stream) and with caller-bound or imported output (the
+ * calibration frames must not land in memory somebody else owns).  Results of frames are unaffected: bit-identical.               */
 int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [4] or NULL */);
 
 /* ---- introspection for tests and the bench -------------------------------- */

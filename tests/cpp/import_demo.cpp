@@ -3,7 +3,12 @@
 // (the reference's Vulkan renderer: INTEGRATION.md section B) or a second process does with the exported maps instead of the
 // reference's staging-buffer round trip (WaterSurfaceMesh.cpp:642-755).
 //   import_demo <fd> <bytes> <disp_offset> <nrm_offset> <map_bytes> <out_file>
+// With "-" as the file it stays alive as the importer of a running producer: every line "r" on stdin makes it read both maps
+// through the import at once and answer "SUM <checksum>" (sum of word_i * (i + 1) over the 32-bit words, mod 2^64); "q" ends it.
 #include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
 
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +34,22 @@ int main(int argc, char** argv)
     void* base = nullptr;
     CHECK(hipExternalMemoryGetMappedBuffer(&base, ext, &bd));
     std::vector<unsigned char> host(2 * map_bytes);
+    if (std::strcmp(argv[6], "-") == 0) {
+        std::printf("IMPORT_READY\n");
+        std::fflush(stdout);
+        char line[64];
+        while (std::fgets(line, sizeof line, stdin) && line[0] == 'r') {
+            CHECK(hipMemcpy(host.data(), static_cast<char*>(base) + doff, map_bytes, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(host.data() + map_bytes, static_cast<char*>(base) + noff, map_bytes, hipMemcpyDeviceToHost));
+            uint64_t sum = 0;
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(host.data());
+            for (size_t i = 0; i < host.size() / 4; ++i) sum += (uint64_t)w[i] * (uint64_t)(i + 1);
+            std::printf("SUM %llu\n", (unsigned long long)sum);
+            std::fflush(stdout);
+        }
+        CHECK(hipDestroyExternalMemory(ext));
+        return 0;
+    }
     CHECK(hipMemcpy(host.data(), static_cast<char*>(base) + doff, map_bytes, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(host.data() + map_bytes, static_cast<char*>(base) + noff, map_bytes, hipMemcpyDeviceToHost));
     FILE* f = std::fopen(argv[6], "wb");

@@ -203,9 +203,10 @@ def test_abi_header_is_plain_c99(abi, tmp_path):
 def test_missing_extension_fails_loudly():
     """No silent fallback: without the built .so the package refuses to work."""
     code = ("import watersurfacerendering_amd as W\n"
+            "from watersurfacerendering_amd import _abi\n"
+            "_abi.LIB_PATH = '/nonexistent/libocean_hip.so'\n"
             "try:\n    W.OceanBatch(64)\nexcept ImportError as e:\n    print('LOUD', e)\n")
-    env = dict(os.environ, OCEAN_HIP_LIB="/nonexistent/libocean_hip.so")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
     assert "LOUD" in r.stdout and "no CPU fallback" in r.stdout.replace("There is no CPU fallback", "no CPU fallback")
 
 

@@ -241,6 +241,58 @@ def test_exported_maps_are_read_by_another_process_through_the_dmabuf(tmp_path):
     b.close()
 
 
+def test_importer_sees_every_frame_right_after_the_synchronous_call(tmp_path):
+    """The ordering contract of include/ocean.h for readers OUTSIDE the context's streams: a completion record
+    is not a memory fence, so once a map set has been exported ocean_compute_waves / ocean_wait_frame synchronise the frame's stream instead
+    of polling.  A second process keeps the dma-buf imported (tests/cpp/import_demo.cpp in its loop mode) and reads both maps the moment the
+    producer's call returns -- no read-out, no ocean_synchronize in between -- 200 frames, synchronous and tracked asynchronous + wait, each
+    bit-exact against a twin context that is read out the usual way."""
+    import os
+    import subprocess
+    import watersurfacerendering_amd as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "import_demo"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    os.path.join(root, "tests", "cpp", "import_demo.cpp"), "-o", str(exe), "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    n, tiles = 512, 2
+    b = W.OceanBatch(n, tiles, 0)
+    twin = W.OceanBatch(n, tiles, 0)
+    b.prepare(SEED + 9); twin.prepare(SEED + 9)
+    b.compute_waves(0.0)
+    fd, doff, noff, nbytes, _ = b.export_maps()
+    map_bytes = tiles * n * n * 16
+    child = subprocess.Popen([str(exe), str(fd), str(nbytes), str(doff), str(noff), str(map_bytes), "-"], pass_fds=(fd,),
+                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+    weights = np.arange(1, 2 * map_bytes // 4 + 1, dtype=np.uint64)
+    try:
+        assert child.stdout.readline().strip() == "IMPORT_READY"
+        b.set_frame_tracking(True)
+        for j in range(200):
+            t = 0.37 * j
+            if j % 2 == 0:
+                amp = b.compute_waves(t)                       # the reference's call shape
+            else:
+                b.compute_waves_async(t)                       # tracked frame + wait: the same contract
+                amp = b.wait_frame()
+            child.stdin.write("r\n"); child.stdin.flush()      # the importer reads NOW
+            line = child.stdout.readline().split()
+            assert line and line[0] == "SUM", line
+            amp_t = twin.compute_waves(t)
+            d, q = twin.read_maps()
+            words = np.concatenate([d.reshape(-1), q.reshape(-1)]).view(np.uint32).astype(np.uint64)
+            want = int((words * weights).sum(dtype=np.uint64))
+            assert int(line[1]) == want, f"frame {j}: the importer read something else than the finished maps"
+            assert np.array_equal(np.asarray(amp), np.asarray(amp_t))
+        child.stdin.write("q\n"); child.stdin.flush()
+        assert child.wait(timeout=60) == 0
+    finally:
+        if child.poll() is None:
+            child.kill()
+        os.close(fd)
+    b.close(); twin.close()
+
+
 def test_python_mirror_async_pair_matches_the_blocking_call():
     """WSTessendorf.ComputeWavesAsync() / Wait() (the mirror of include/WSTessendorf.hpp's opt-in pair): A at once, the previous frame's maps
     until Wait(), then exactly the blocking call's frame."""

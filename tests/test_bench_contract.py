@@ -88,6 +88,49 @@ def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
     assert ref["cores"] >= 1 and "sample" in ref and ("FFTW not available" in ref["sample"] or ref["fft"] == "fftw3f")
     assert ref["host"]["nproc"] >= 1
     assert strong["value"] > 0 and "work-shared" in strong["sample"]
+    # `cores` is the USABLE CPU count (min of the affinity mask and the cgroup quota) -- the team the sample really ran
+    # with -- and the host's logical CPU count stands beside it (round 3 printed cores = 256 next to a quota of 16)
+    usable, quota, aff, nproc = bench.usable_cpus()
+    assert 1 <= usable <= aff <= nproc and (quota is None or usable <= int(quota + 0.999999))
+    assert ref["cores"] == min(usable, ref["host"]["omp_max_threads"]) and ref["nproc"] == nproc == ref["host"]["nproc"]
+    assert ref["host"]["usable_cpus"] == usable and f"{ref['cores']} threads" in ref["sample"]
+
+
+def test_timed_regions_are_repeated_and_reported_as_median_with_spread(bench):
+    """SURVEY.md 8d / VERDICT r03 #4: the timed region of --steps frames is repeated K >= 7 times inside one invocation; ms_per_step is the
+    median region, p10 / p90 stand beside it.  (The GPU side is exercised by tests/test_parity_bench_regimes.py; here: the defaults and
+    that the line keeps the contract's keys with the statistics added.)"""
+    a = bench.parse([])
+    assert a.regions >= 7
+    assert bench.parse(["--regions", "11"]).regions == 11
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("ms_per_step_p10", "ms_per_step_p90", "ms_per_step_median", "steps_per_region", "p10_ms_per_step", "p90_ms_per_step"):
+        assert key in src
+    names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
+    roof = bench.roofline_object(2048, 1, names, [0.025, 0.022, 0.0175], None, 1, 0.066, 66.0, 73.0)
+    line = bench.build_line(a, 1, 2048, 1, 2e4, 0.05, roof, None, {}, None, None)
+    assert line["steps"] == a.steps and line["warmup"] == a.warmup and line["ms_per_step"] == 0.05
+
+
+def test_config4_check_compares_saved_gpu_rows_with_the_float64_oracle(bench, tmp_path):
+    """The CPU-baseline child's second job (VERDICT r03 #6a): frames the GPU side saved are compared with the float64 oracle per variant.
+    Here the 'GPU frames' are the oracle's own float32-FFT frame (error at the fp32 floor) and a perturbed copy (error visible)."""
+    import numpy as np
+    from oracle import oracle as O
+    n, t = 64, 1.0
+    xi = O.gauss_xi_numpy(bench.SEED, n)
+    o = O.Oracle(n)
+    o.prepare(xi=xi)
+    amp, d, q = o.compute_waves(t, fft=O.FFT_F32)
+    rows = np.arange(0, n, 8)
+    maps = np.concatenate([d[rows], q[rows]], axis=-1)
+    bad = maps.copy(); bad[..., 0] += 1e-2 * np.abs(d[..., 0]).max()
+    path = tmp_path / "check.npz"
+    np.savez(path, n=n, t=t, rows=rows, names=np.array(["fp32", "broken"]), xi=xi, maps_fp32=maps, amp_fp32=amp, maps_broken=bad, amp_broken=amp)
+    r = bench.check_frames_against_oracle(str(path))
+    assert r["tile_size"] == n and r["rows_compared"] == len(rows)
+    assert r["variants"]["fp32"]["max_err_over_max_channel"] < 1e-5 and r["variants"]["fp32"]["amplitude_rel_err"] < 1e-6
+    assert 0.9e-2 < r["variants"]["broken"]["max_err_over_max_channel"] < 1.1e-2
 
 
 def test_committed_profile_summaries_match_the_kernels(bench):

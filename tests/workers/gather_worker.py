@@ -44,6 +44,23 @@ def main():
             ref = W.OceanBatch(n, 1, local); ref.prepare(seed + per * (world - 1)); ref.compute_waves(0.5)
             rd, rq = ref.read_maps(); ref.close()
             ok = ok and np.array_equal(got[0, world - 1, 0].numpy(), rd[0]) and np.array_equal(got[1, world - 1, 0].numpy(), rq[0])
+            # ... and the first run on real multi-GPU hardware is a PARITY run too: one gathered tile of EVERY rank (its last one, so
+            # that the offset inside a rank's block counts) against the float64 oracle of that global tile index -- what arrived over
+            # xGMI is the ocean the reference would synthesise for (seed, t), 1e-5 of every channel's maximum
+            from oracle import oracle as O
+            for r in range(world):
+                g = r * per + (per - 1)
+                o = O.Oracle(n)
+                o.prepare(seed=seed + g)
+                _, od, oq = o.compute_waves(0.5, fft=O.FFT_F64)
+                for m, want in ((0, od), (1, oq)):
+                    have = got[m, r, per - 1].numpy().astype(np.float64)
+                    for c in range(4):
+                        den = max(float(np.abs(want[..., c]).max()), 1e-30)
+                        err = float(np.abs(have[..., c] - want[..., c]).max()) / den
+                        if err > 1e-5:
+                            print(f"GATHER_PARITY rank {r} tile {g} map {m} channel {c}: {err:.3e}", flush=True)
+                            ok = False
     b.comm_destroy(); b.close()
     dist.barrier()
     if rank == 0:

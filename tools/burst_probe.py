@@ -1,6 +1,8 @@
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 b = W.OceanBatch(2048, 1, 0); b.set_pipeline_depth(3); b.prepare(1)
 DT=0.016

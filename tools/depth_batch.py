@@ -1,5 +1,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 n = int(sys.argv[1]); tiles = int(sys.argv[2]); depths = [int(x) for x in sys.argv[3].split(",")]
 out = []

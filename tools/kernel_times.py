@@ -2,6 +2,8 @@
 usage: OCEAN_HIP_LIB=... python tools/kernel_times.py N [tiles] [frames]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 n = int(sys.argv[1]); tiles = int(sys.argv[2]) if len(sys.argv) > 2 else 1; frames = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 b = W.OceanBatch(n, tiles, 0)

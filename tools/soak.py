@@ -2,6 +2,8 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 for n, frames, depth in [(2048, 30000, 3), (512, 200000, 4), (1024, 50000, 2)]:
     b = W.OceanBatch(n, 1, 0); b.prepare(9); b.set_pipeline_depth(depth)

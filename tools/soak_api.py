@@ -7,6 +7,8 @@ usage: soak_api.py [operations] [seed]"""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 ops = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

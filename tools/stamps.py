@@ -2,6 +2,8 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 from watersurfacerendering_amd import _abi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048

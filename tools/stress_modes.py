@@ -3,6 +3,8 @@ producing the maps a fresh single-purpose context produces (developer tool)."""
 import sys, os, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 bad = 0
 for n, tiles in [(64, 5), (512, 2), (2048, 1)]:

@@ -1,6 +1,8 @@
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 for n, tiles in [(16, 4096), (64, 2048), (256, 256), (1024, 16)]:
     b = W.OceanBatch(n, tiles, 0); b.prepare(77)

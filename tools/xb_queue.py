@@ -4,6 +4,8 @@ usage: xb_queue.py [contexts per k]"""
 import ctypes as C, os, sys, time
 T0 = time.perf_counter()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 hip = C.CDLL("libamdhip64.so")
 from watersurfacerendering_amd import _abi

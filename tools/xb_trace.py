@@ -11,6 +11,8 @@ if mode != "none":
     import torch
     keep = [torch.cuda.Stream() for _ in range(2 if mode == "two_streams_before" else 1)]
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
 from watersurfacerendering_amd import _abi
 L = _abi.lib()

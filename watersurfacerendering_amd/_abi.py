@@ -12,7 +12,7 @@ import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _BUILT_LIB = os.path.join(_PKG, "libocean_hip.so")
-LIB_PATH = os.environ.get("OCEAN_HIP_LIB") or _BUILT_LIB   # env override: kernel A/B builds only
+LIB_PATH = _BUILT_LIB      # the one library this package loads (developer A/B scripts under tools/ re-point it themselves: tools/devlib.py)
 CSRC = os.path.join(_PKG, "csrc")
 
 OCEAN_OK = 0
@@ -65,15 +65,24 @@ class LaunchInfo(C.Structure):
                 ("lds_bytes", C.c_uint32), ("flags", C.c_uint32), ("per_workgroup", C.c_uint32), ("mode", C.c_uint32)]
 
 
+last_build = ""      # what the most recent build() did, for the caller to log
+
+
 def build(force: bool = False) -> str:
     """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  force (or OCEAN_FORCE_REBUILD=1 in
     the environment) rebuilds every translation unit from scratch instead of trusting file times."""
     force = force or os.environ.get("OCEAN_FORCE_REBUILD", "") not in ("", "0")
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"))
-    stale = (not os.path.exists(_BUILT_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_BUILT_LIB) for s in srcs)
+    newer = [] if not os.path.exists(_BUILT_LIB) else [s for s in srcs if os.path.getmtime(s) > os.path.getmtime(_BUILT_LIB)]
+    stale = (not os.path.exists(_BUILT_LIB)) or bool(newer)
+    global last_build
     if force or stale:
+        why = "forced" if force else ("no library yet" if not os.path.exists(_BUILT_LIB) else "sources newer than the library: " + ", ".join(os.path.basename(s) for s in newer))
         subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
+        last_build = f"rebuilt libocean_hip.so ({why})"
+    else:
+        last_build = "libocean_hip.so is up to date with every source (no compile; OCEAN_FORCE_REBUILD=1 rebuilds from scratch)"
     return _BUILT_LIB
 
 
@@ -164,12 +173,7 @@ def lib() -> C.CDLL:
         "ocean_algorithmic_bytes_per_launch": (i32, [P, i32]),
     }
     for name, (res, args) in sig.items():
-        try:
-            fn = getattr(L, name)
-        except AttributeError:
-            if os.environ.get("OCEAN_HIP_LIB"):   # older A/B build without a newer entry point
-                continue
-            raise
+        fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     _lib = L
     return L

@@ -47,6 +47,7 @@ static void free_device(ocean_ctx* c)
     c->prepared = false;
     // nothing of the old buffers may be referred to any more: no frame, no chain to read out, no mips of the old size
     c->have_frame = false; c->last_set = 0; c->frame_ctr = 0; c->mips_ready = false; c->grid_vertices = 0;
+    c->maps_shared = false;             // the exported / handed-out maps are gone with the buffers
 }
 
 static void free_set(ocean_ctx* c, int i)
@@ -474,9 +475,11 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
     a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
-    c->tracked[set] = track;
-    if (++c->seq[set] == 0) c->seq[set] = 1;            // never 0: a fresh record buffer reads as "no frame"
-    a.frame_seq = c->seq[set];
+    // the chain's sequence number and tracking state are committed only once the launches have succeeded: a failed enqueue leaves
+    // have_frame / last_set / seq describing the previous frame, whose records and maps are intact
+    unsigned frame_seq = c->seq[set] + 1u;
+    if (frame_seq == 0) frame_seq = 1;                  // never 0: a fresh record buffer reads as "no frame"
+    a.frame_seq = frame_seq;
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
     a.toff = c->use_toff ? c->toff : nullptr;
@@ -535,6 +538,8 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     else if (c->n == 4096) e = ocean_launch_frame_4096(c, a, stream_maps, st, marks);
     else return OCEAN_E_UNSUPPORTED;
     if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
+    c->seq[set] = frame_seq;
+    c->tracked[set] = track;
     if (pipe) c->frame_ctr++;
     c->have_frame = true;
     c->last_set = set;
@@ -574,7 +579,13 @@ static int wait_frame(ocean_ctx* c, int set)
     const unsigned want = c->seq[set];
     const volatile uint4* rec = c->done_rec[set];
     bool synced = false;
-    if (!c->tracked[set]) {           // the records arrive early in the frame's last kernel: only the stream tells when it has finished
+    // A completion record says that every workgroup of the frame has issued its stores; it is not a memory fence.  Readers on the
+    // context's own streams are ordered by the stream.  Wherever somebody ELSE may read the maps right after this call -- caller-bound
+    // or imported output (ocean_bind_output / ocean_bind_output_dmabuf), a map set that has been exported (ocean_export_maps) or whose
+    // device pointers have been handed out (ocean_device_maps) -- the wait is a stream synchronisation, i.e. the end-of-kernel release
+    // and write-back have happened when it returns: the old "synchronous" guarantee, where external readers exist.
+    const bool external = c->ext_disp || c->ext_nrm || c->maps_shared;
+    if (!c->tracked[set] || external) {           // (untracked: the records arrive early in the frame's last kernel, only the stream tells when it has finished)
         HIP_TRY(hipStreamSynchronize(stream_of(c, set)));
         synced = true;
     }
@@ -726,6 +737,7 @@ int ocean_device_maps(ocean_t* c, void** d_disp, void** d_nrm)
     if (!c) return OCEAN_E_INVALID;
     if (d_disp) *d_disp = c->ext_disp ? (void*)c->ext_disp : (void*)c->dispN[c->last_set];
     if (d_nrm) *d_nrm = c->ext_nrm ? (void*)c->ext_nrm : (void*)c->nrmN[c->last_set];
+    c->maps_shared = true;              // somebody outside the context's streams may read the maps from now on: see wait_frame
     return OCEAN_OK;
 }
 
@@ -743,6 +755,7 @@ int ocean_export_maps(ocean_t* c, int* dmabuf_fd, size_t* disp_offset, size_t* n
     int fd = -1;
     HIP_TRY(hipMemGetHandleForAddressRange(&fd, (hipDeviceptr_t)c->dispN[set], c->maps_bytes[set], hipMemRangeHandleTypeDmaBufFd, 0));
     *dmabuf_fd = fd;
+    c->maps_shared = true;              // an importer reads the maps outside the context's streams from now on: see wait_frame
     if (disp_offset) *disp_offset = 0;
     if (nrm_offset) *nrm_offset = (size_t)c->tiles * c->n * c->n * sizeof(float4);
     if (bytes) *bytes = c->maps_bytes[set];
@@ -772,7 +785,7 @@ int ocean_bind_output_dmabuf(ocean_t* c, int dmabuf_fd, size_t bytes, size_t dis
     if (!c || dmabuf_fd < 0) return OCEAN_E_INVALID;
     const size_t map_bytes = (size_t)c->tiles * c->n * c->n * sizeof(float4);
     if ((disp_offset | nrm_offset) & 15u) return OCEAN_E_INVALID;
-    if (disp_offset + map_bytes > bytes || nrm_offset + map_bytes > bytes) return OCEAN_E_INVALID;
+    if (map_bytes > bytes || disp_offset > bytes - map_bytes || nrm_offset > bytes - map_bytes) return OCEAN_E_INVALID;     // (no sum that could wrap)
     if (disp_offset < nrm_offset + map_bytes && nrm_offset < disp_offset + map_bytes) return OCEAN_E_INVALID;      // the two maps overlap
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
@@ -1059,6 +1072,11 @@ int ocean_select_streams(ocean_t* c, uint32_t frames, float* us_per_frame)
     if (!c || frames == 0) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
     if (c->user) return OCEAN_E_UNSUPPORTED;               // a caller-owned stream: nothing to choose
+    // the calibration frames go to whatever output is bound: never into memory the caller or a renderer owns
+    if (c->ext_disp || c->ext_nrm) return OCEAN_E_UNSUPPORTED;
+    // (assumes the context's first four streams sit on four distinct hardware queues, which holds when they are the process's first
+    //  streams under the default GPU_MAX_HW_QUEUES = 4; other streams created earlier -- a framework's -- shift the mapping, and the
+    //  ranking then compares whatever queues the four streams did land on: still a valid order of the context's own streams)
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
     constexpr int CAND = 4;

@@ -64,6 +64,8 @@ struct ocean_ctx {
     size_t maps_bytes[MAXD] = {};  // size of that allocation (a whole number of 2 MiB pages: ocean_export_maps)
     float4* ext_disp = nullptr;
     float4* ext_nrm = nullptr;
+    bool maps_shared = false;      // the internal maps are visible outside the context's streams (ocean_export_maps, ocean_device_maps) until they
+                                   //   are re-allocated: ocean_wait_frame / ocean_compute_waves then synchronise the stream (ocean_api.hip: wait_frame)
     hipExternalMemory_t import_mem = nullptr;   // ocean_bind_output_dmabuf: the imported memory object ext_disp / ext_nrm point into
     void* import_base = nullptr;
     float* toff = nullptr;
