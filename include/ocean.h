@@ -399,8 +399,10 @@ enum {
     OCEAN_LAUNCH_FP16_SPECTRUM   = 16,   /* z pass reads the half2 copy of h0 (wave-uniform branch, no instantiation)   */
     OCEAN_LAUNCH_FP32_DISPERSION = 32,   /* z pass reads the fp32 dispersion array: some multiple of the base frequency
                                             needs more than 16 bits (wave-uniform branch)                               */
-    OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64   /* z pass: the columns of the last, partially filled round of workgroups are
+    OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64,  /* z pass: the columns of the last, partially filled round of workgroups are
                                             split over two workgroups each (serial frames of one tile)                  */
+    OCEAN_LAUNCH_PERSISTENT      = 128   /* z pass: persistent workgroups (grid = what the device keeps resident), each
+                                            working through several columns with the next column's loads in flight      */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

@@ -401,20 +401,20 @@ __device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In&
 // The call may start while other waves still read `lds` from a previous call:
 // the first LDS write is preceded by a barrier.
 template <int N, int C, int T, class P = Plan<N>, int LM = 0, class In, class Out>
-__device__ __forceinline__ void batch_fft(c32* lds, const TwiddleRegs<N, C, T, P, LM>& twr, int tid, In& in, Out& out)
+__device__ __forceinline__ void batch_fft(c32* lds, TwiddleRegs<N, C, T, P, LM>& twr, int tid, In& in, Out& out)
 {
     static_assert(P::product() == N, "radix plan does not match the transform length");
     // Launder the base twiddles: otherwise the compiler hoists the whole power chain
     // (up to 15 complex per stage) out of consecutive transforms and keeps ~90 VGPRs
     // live across them -- recomputing 14 products per butterfly is far cheaper than
-    // the occupancy that costs.
-    TwiddleRegs<N, C, T, P, LM> local = twr;
+    // the occupancy that costs.  In place (round 3 laundered a COPY per transform, which kept two sets of
+    // base twiddles alive while a transform ran), and only the stages that have twiddles (the first stage's are the constant 1).
 #pragma unroll
-    for (int s = 0; s < P::S; ++s)
+    for (int s = 1; s < P::S; ++s)
 #pragma unroll
-        for (int u = 0; u < TwiddleRegs<N, C, T, P, LM>::itmax(); ++u)
-            asm volatile("" : "+v"(local.w[s][u].x), "+v"(local.w[s][u].y));
-    run_stages<N, C, T, P, 0, 1, LM>(lds, local, tid, in, out);
+        for (int u = 0; u < TwiddleRegs<N, C, T, P, LM>::it_of(s); ++u)
+            asm volatile("" : "+v"(twr.w[s][u].x), "+v"(twr.w[s][u].y));
+    run_stages<N, C, T, P, 0, 1, LM>(lds, twr, tid, in, out);
 }
 
 // Mapping of the FIRST stage: work item w = tid + u*T reads inputs

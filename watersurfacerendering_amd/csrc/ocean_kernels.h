@@ -468,6 +468,40 @@ __device__ __forceinline__ void animate_with_mirror(float2 h0a, float2 h0b, floa
     bv = height_re(h0b.x, h0b.y, c, s);
 }
 
+// ---- phase 1 in two halves, for the persistent z pass (k_zpass<..., PERS>) ---------------------------------------------------------
+// A persistent workgroup works through several spectrum columns; the raw loads of column k+1 (ZRaw: nine registers per element pair in the
+// usual form of the spectrum -- fp32 h0, 16-bit dispersion) are ISSUED before the transforms of column k and CONSUMED after them, so the
+// load burst of a column travels under the previous column's butterflies, exchanges and stores instead of in front of its own.  Nothing
+// but the loads happens in zpass_load_raw -- any arithmetic on a loaded value would make the wave wait for it there --, and
+// zpass_animate_raw does exactly what zpass_load_pair + animate_with_mirror do, operation for operation: frames are bit-identical.
+struct ZRaw {
+    float4 ha;            // a(n), a(n+1): elements n, n+1 of column nb
+    float2 hb0, hb1;      // b(N-n), b(N-n-1): their point mirrors in column (N-nb)%N
+    unsigned wq;          // the two 16-bit multiples of the base frequency (elements n, n+1)
+};
+template <int N>
+__device__ __forceinline__ void zpass_load_raw(const FrameArgs& a, int tile, int col, int n, ZRaw& r)
+{
+    const size_t n2 = (size_t)N * N;
+    const int mcol = (N - col) & (N - 1);
+    const size_t g = (size_t)col * N + n;
+    const size_t m0 = (size_t)mcol * N + ((N - n) & (N - 1)), m1 = (size_t)mcol * N + (N - n - 1);
+    const float2* __restrict__ h0 = a.h0 + tile * n2;
+    r.ha = *reinterpret_cast<const float4*>(h0 + g);
+    r.hb0 = h0[m0]; r.hb1 = h0[m1];
+    r.wq = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
+}
+// S+ (a0 + b0)/2, (a1 + b1)/2 of the pair, or (a0, a1) for the Nyquist column; *sm = S-(n) = (a0 - b0)/2
+__device__ __forceinline__ float2 zpass_animate_raw(const ZRaw& r, float base, float t, bool col0, float* sm)
+{
+    const float w0 = mul_nocontract((float)(r.wq & 0xffffu), base), w1 = mul_nocontract((float)(r.wq >> 16), base);
+    float a0, b0, a1, b1;
+    animate_with_mirror(make_float2(r.ha.x, r.ha.y), r.hb0, w0, t, a0, b0);
+    animate_with_mirror(make_float2(r.ha.z, r.ha.w), r.hb1, w1, t, a1, b1);
+    *sm = 0.5f * (a0 - b0);
+    return col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
+}
+
 // ---- half-spectrum storage geometry -------------------------------------------
 #ifndef OCEAN_ZTILE
 #define OCEAN_ZTILE 8          // rows per block of the intermediates (fp32: 64-byte pieces)
@@ -615,10 +649,15 @@ __device__ __forceinline__ c32 zpass_input(float kx, float kx2, float kz, float 
     else return make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
 }
 
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `hook` runs once per thread, with the first output of the LAST stage of the column's last batch: where the persistent z pass issues
+// the next column's loads -- the radix-4 last stage holds four complex values at a time, the stages before it sixteen and a twiddle
+// chain, so the nine registers per element pair in flight fit there without costing the kernel a workgroup per CU.
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC, class Hook = NoHook>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
-                                                 const TwiddleRegs<N, ZC, T, P>& twr, float kx, float sm0, int tid,
-                                                 int tile, int nb, int batches /* bit 0: {pair 0, pair 1}, bit 1: {pair 2, height} */)
+                                                 TwiddleRegs<N, ZC, T, P>& twr, float kx, float sm0, int tid,
+                                                 int tile, int nb, int batches /* bit 0: {pair 0, pair 1}, bit 1: {pair 2, height} */,
+                                                 Hook hook = Hook())
 {
     using HF = Half<N>;
     const float kx2 = kx * kx;
@@ -740,6 +779,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
+            if (u == 0 && i == 0) hook();
             if (c) {
                 if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
                 else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
@@ -757,7 +797,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 // of two interleaved transforms, batch g = pair g (g = 3: the height, or pair 3 of the Jacobian mode) of BOTH columns, so that
 // lanes 0-31 / 32-63 of a last-stage store hold the same 32 rows of column nb0 / nb0 + 1: 4 x (64 + 64) contiguous bytes.
 template <int N, int T, class P, bool ZNT, bool Z16, bool FAST>
-__device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned char* smem, const TwiddleRegs<N, 2, T, P>& twr,
+__device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned char* smem, TwiddleRegs<N, 2, T, P>& twr,
                                                   int tid, int tile, int nb0)
 {
     using HF = Half<N>;
@@ -861,6 +901,88 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     }
 }
 
+// Persistent form of the one-column z pass (k_zpass<..., PERS = true>): the grid is the number of workgroups the device keeps resident, and
+// a workgroup works through the columns job, job + gridDim.x, ... of its tile.  The raw spectrum loads of its NEXT column are issued
+// before the transforms of the current one (zpass_load_raw / zpass_animate_raw), the kz table and the twiddles are set up once, and no
+// column is animated twice (the split last round of the one-shot form animates 257 columns of a serial 2048^2 frame twice).
+// Barriers: the S+ table of column k+1 is written after the transforms of column k -- every wave is past the last first stage that reads
+// it, because two stage barriers follow that stage --, and S-(0) lives outside the FFT image, which the slower waves may still be reading.
+template <int N, int T, class P, bool ZNT, bool Z16>
+__device__ __forceinline__ void zpass_persistent(const FrameArgs& a, unsigned char* smem, TwiddleRegs<N, 2, T, P>& twr, const int tid0, int tile)
+{
+    static_assert(zpass_columns<N>() == 2, "two-transform batches");
+    constexpr int NC = N / 2 + 1;                       // columns 0 .. N/2
+    constexpr int PAIRS = N / 2, P1 = PAIRS / T;
+    static_assert(PAIRS % T == 0 && P1 >= 1 && P1 <= 2, "prefetch registers per thread");
+    c32* fbuf = reinterpret_cast<c32*>(smem);
+    float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());
+    float* kzt = sp + N;
+    float* sm = kzt + N;                                // [0]: S-(0) of the current column
+    const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
+    const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
+    const float base = a.base_freq[tile];
+    int job = (int)blockIdx.x;
+    ZRaw r[P1];
+    {
+        const int nb0 = xcd_swizzle(job, NC);           // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
+#pragma unroll
+        for (int u = 0; u < P1; ++u) zpass_load_raw<N>(a, tile, nb0, 2 * (tid0 + u * T), r[u]);
+#pragma unroll
+        for (int u = 0; u < P1; ++u) {
+            const int n = 2 * (tid0 + u * T);
+            *reinterpret_cast<float2*>(kzt + n) = *reinterpret_cast<const float2*>(k1 + n);
+        }
+    }
+    if (blockIdx.x == 0 && tid0 == 0) {
+        // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
+        a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
+        a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
+    }
+    // one column: S+ from the registers, barrier, the four transforms; the next column's loads are issued from inside the last stage
+    auto column = [&](auto col0_tag, const int nb, const int nb_next, const bool has_next) {
+        constexpr bool COL0 = decltype(col0_tag)::value;
+        // (the thread index is laundered once per column: everything derived from it -- load offsets, LDS addresses, the store bases of
+        //  the last stages -- is then recomputed per column, a few instructions, instead of being hoisted out of the loop into
+        //  registers that would cost the third workgroup per CU)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int u = 0; u < P1; ++u) {
+            const int n = 2 * (tid + u * T);
+            float smv;
+            *reinterpret_cast<float2*>(sp + n) = zpass_animate_raw(r[u], base, t, COL0, &smv);
+            if (n == 0) sm[0] = smv;
+        }
+        __syncthreads();
+        const float sm0 = sm[0];
+        auto prefetch = [&]() {
+#ifndef OCEAN_PERS_BRANCH
+            (void)has_next;         // (the last column of a workgroup loads some column once more, unused: cheaper than a branch around the loads)
+#else
+            if (has_next)
+#endif
+            {
+#pragma unroll
+                for (int u = 0; u < P1; ++u) zpass_load_raw<N>(a, tile, nb_next, 2 * (tid + u * T), r[u]);
+            }
+        };
+        zpass_transforms<N, T, P, COL0, ZNT, Z16, 2>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, 3, prefetch);
+    };
+    // the Nyquist column 0 (xcd_swizzle(0, .) == 0: workgroup 0's first job) has a code path of its own; it stays outside the loop
+    if (job == 0) {
+        const int next = (int)gridDim.x;
+        column(std::true_type{}, 0, next < NC ? xcd_swizzle(next, NC) : 0, next < NC);
+        job = next;
+        if (job >= NC) return;
+    }
+    for (;;) {
+        const int next = job + (int)gridDim.x;
+        column(std::false_type{}, xcd_swizzle(job, NC), next < NC ? xcd_swizzle(next, NC) : 0, next < NC);
+        if (next >= NC) break;
+        job = next;
+    }
+}
+
 // ============================================================================
 // k_zpass (first pass, z axis): workgroup = spectrum COLUMN nb (kx index,
 // blockIdx.x in [0, N/2]); mirror column nbb = (N-nb)%N.  Both are contiguous
@@ -880,11 +1002,21 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
 // (two columns per workgroup at 2048: 59 KB of LDS allow two workgroups per CU, i.e. four waves per SIMD and 128 VGPRs; the
 //  80-VGPR cap of the one-column form would only make that variant spill)
-template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true>
-__global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_waves<N>()) k_zpass(const FrameArgs a)
+#ifndef OCEAN_ZLB
+#define OCEAN_ZLB ((ZW == 2 && N == 2048) ? 4 : zpass_min_waves<N>())
+#endif
+template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true, bool PERS = false>
+__global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ZC = zpass_columns<N>();
+    if constexpr (PERS) {
+        static_assert(ZW == 1 && FAST, "the persistent form exists for the usual form of the spectrum, one column at a time");
+        TwiddleRegs<N, 2, T, P> twp;
+        twp.load(a.tw, threadIdx.x);
+        zpass_persistent<N, T, P, ZNT, Z16>(a, smem, twp, threadIdx.x, blockIdx.y);
+        return;
+    }
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // ZC interleaved transforms
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, ZC>());   // S+ [N]
     float* kzt = sp + N;                                                   // kz table [N]
@@ -974,6 +1106,9 @@ __global__ void __launch_bounds__(T, (ZW == 2 && N == 2048) ? 4 : zpass_min_wave
 #endif
         one_column(nb, batches);
     }
+#ifdef OCEAN_EXP_ENDWAIT      // experiment: the workgroup stays until its stores have been taken (what a persistent workgroup's next column waits for)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 // resident z-pass workgroups per CU (lower bound from LDS, threads and the register cap of the launch bounds)
@@ -990,6 +1125,11 @@ template <int N, int ZW = 1> constexpr size_t zpass_lds_bytes()
 {
     return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * (1 + ZW) * N;
 }
+// the persistent form keeps S-(0) outside the FFT image
+template <int N> constexpr size_t zpass_lds_bytes_persistent() { return zpass_lds_bytes<N, 1>() + 16; }
+template <int N> constexpr bool zpass_has_persistent() { return zpass_columns<N>() == 2 && N >= 1024; }
+// where the launcher picks it (stream_maps: ocean_ctx.h; bit 4 = the frame has the device to itself)
+template <int N> inline bool zpass_persistent_pays(int stream_maps, unsigned tiles) { (void)stream_maps; (void)tiles; return false; }
 
 // ---- x-pass helpers ------------------------------------------------------------------
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the

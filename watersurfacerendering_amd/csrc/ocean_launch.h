@@ -48,6 +48,13 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, lds_rows2)) != hipSuccess) return e;
 #define OCEAN_ALLOW_Z2(fast) OCEAN_ALLOW_Z(false, false, fast) OCEAN_ALLOW_Z(true, false, fast) OCEAN_ALLOW_Z(false, true, fast) OCEAN_ALLOW_Z(true, true, fast)
         OCEAN_ALLOW_Z2(true) OCEAN_ALLOW_Z2(false)
+        if constexpr (zpass_has_persistent<N>()) {
+            constexpr size_t lp = zpass_lds_bytes_persistent<N>();
+            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, 1, true, true>, lp)) != hipSuccess) return e;
+            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, 1, true, true>, lp)) != hipSuccess) return e;
+            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, 1, true, true>, lp)) != hipSuccess) return e;
+            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true, 1, true, true>, lp)) != hipSuccess) return e;
+        }
 #undef OCEAN_ALLOW_Z2
 #undef OCEAN_ALLOW_Z
 #define OCEAN_ALLOW_X(kern, lds) \
@@ -85,6 +92,38 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         FrameArgs za = a;
         za.zfull = (int)gx;
         bool split = false;
+        // the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the other forms' code (FAST)
+        const bool fast = !a.h0h && a.omega_q;
+        // persistent one-column form: as many workgroups as stay resident, each working through its share of the columns with the next
+        // column's loads in flight under the current column's transforms
+        bool pers = false;
+        if constexpr (zpass_has_persistent<N>()) {
+            pers = fast && !zw2 && zpass_persistent_pays<N>(stream_maps, tiles);
+#ifdef OCEAN_DEVELOPER
+            static const char* const pers_env = getenv("OCEAN_ZPERS");            // 0 / 1
+            if (pers_env) pers = fast && !zw2 && atoi(pers_env) != 0;
+#endif
+        }
+        if (pers) {
+            if constexpr (zpass_has_persistent<N>()) {
+                if (c->pers_n != (uint32_t)N) {         // resident workgroups per CU of the persistent kernel, asked of the runtime once per tile size
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zpass<N, G::T_ROWS, typename G::PR, false, false, 1, true, true>,
+                                                                     G::T_ROWS, zpass_lds_bytes_persistent<N>()) != hipSuccess || per_cu < 1)
+                        per_cu = zpass_blocks_per_cu<N, G::T_ROWS>();
+                    c->pers_slots = (uint32_t)per_cu * (uint32_t)c->cu_count;
+                    c->pers_n = (uint32_t)N;
+                }
+            }
+            unsigned slots = c->pers_slots;
+#ifdef OCEAN_DEVELOPER
+            static const char* const pg_env = getenv("OCEAN_ZPERS_GRID");          // resident workgroups assumed, all tiles together
+            if (pg_env) slots = (unsigned)atoi(pg_env);
+#endif
+            unsigned per_tile = slots / tiles;
+            if (per_tile < 1) per_tile = 1;
+            if (per_tile < gx) gx = per_tile;
+        } else
         if ((stream_maps & 16) && tiles == 1 && zpass_columns<N>() == 2 && !zw2) {
             // serial frames: split the columns of the last, partially filled round over two workgroups each
             const unsigned slots = (unsigned)zpass_blocks_per_cu<N, G::T_ROWS>() * (unsigned)c->cu_count;
@@ -102,10 +141,21 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.lds_bytes = (uint32_t)(zw2 ? lds_rows2 : lds_rows);
             li.flags = ((stream_maps & 4) ? OCEAN_LAUNCH_NT_INTER : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
                        (a.mode == 3 ? OCEAN_LAUNCH_JACOBIAN : 0u) | (a.h0h ? OCEAN_LAUNCH_FP16_SPECTRUM : 0u) |
-                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (split ? OCEAN_LAUNCH_SPLIT_LAST_ROUND : 0u);
+                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (split ? OCEAN_LAUNCH_SPLIT_LAST_ROUND : 0u) |
+                       (pers ? OCEAN_LAUNCH_PERSISTENT : 0u);
+            if (pers) li.lds_bytes = (uint32_t)zpass_lds_bytes_persistent<N>();
         }
-        // the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the other forms' code (FAST)
-        const bool fast = !a.h0h && a.omega_q;
+        if constexpr (zpass_has_persistent<N>()) {
+            if (pers) {
+                constexpr size_t lp = zpass_lds_bytes_persistent<N>();
+                const int v = ((stream_maps & 4) ? 1 : 0) | ((stream_maps & 8) ? 2 : 0);
+                if (v == 0) launch(k_zpass<N, G::T_ROWS, typename G::PR, false, false, 1, true, true>, grid, block, lp, st, marks, za);
+                else if (v == 1) launch(k_zpass<N, G::T_ROWS, typename G::PR, true, false, 1, true, true>, grid, block, lp, st, marks, za);
+                else if (v == 2) launch(k_zpass<N, G::T_ROWS, typename G::PR, false, true, 1, true, true>, grid, block, lp, st, marks, za);
+                else launch(k_zpass<N, G::T_ROWS, typename G::PR, true, true, 1, true, true>, grid, block, lp, st, marks, za);
+            }
+        }
+        if (!pers) {
 #define OCEAN_ZPASS3(znt, z16, fast) \
         do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds_rows2, st, marks, za); break; } } \
              launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds_rows, st, marks, za); } while (0)
@@ -114,6 +164,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #define OCEAN_ZPASS(znt) \
         do { if (stream_maps & 8) OCEAN_ZPASS2(znt, true); else OCEAN_ZPASS2(znt, false); } while (0)
         if (stream_maps & 4) OCEAN_ZPASS(true); else OCEAN_ZPASS(false);
+        }
 #undef OCEAN_ZPASS
 #undef OCEAN_ZPASS2
 #undef OCEAN_ZPASS3
