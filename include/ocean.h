@@ -399,10 +399,11 @@ enum {
     OCEAN_LAUNCH_FP16_SPECTRUM   = 16,   /* z pass reads the half2 copy of h0 (wave-uniform branch, no instantiation)   */
     OCEAN_LAUNCH_FP32_DISPERSION = 32,   /* z pass reads the fp32 dispersion array: some multiple of the base frequency
                                             needs more than 16 bits (wave-uniform branch)                               */
-    OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64,  /* z pass: the columns of the last, partially filled round of workgroups are
-                                            split over two workgroups each (serial frames of one tile)                  */
-    OCEAN_LAUNCH_PERSISTENT      = 128   /* z pass: persistent workgroups (grid = what the device keeps resident), each
-                                            working through several columns with the next column's loads in flight      */
+    OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64,  /* (rounds 2-3: the columns of a partially filled last round of z-pass workgroups split
+                                            over two workgroups each; never set since round 4 -- the single-transform form
+                                            replaced it -- the value stays reserved)                                    */
+    OCEAN_LAUNCH_SINGLE_TRANSFORM = 128  /* z pass: one transform per batch, half the threads (k_zpass_c1): two independent
+                                            workgroups per CU where the two-transform forms fit only one (4096^2)       */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

@@ -2,13 +2,14 @@
 
 One ComputeWaves (reference WSTessendorf.cpp:284-455) is three launches, and the host picks an instantiation of each per
 frame -- store policy of the maps (NTS) and of the intermediates (ZNT), half2 intermediates (Z16), the Jacobian role (JAC),
-one or two spectrum columns per z-pass workgroup (ZW), the split last round, and two wave-uniform branches inside the z
-pass (fp16 copy of the spectrum, fp32 dispersion array) -- from the tile size, the batch size, the pipeline depth, the
-mode and the precisions (ocean_api.hip: enqueue_frame, ocean_launch.h: launch_frame).  `ocean_last_launch` reports what a
+one or two spectrum columns per z-pass workgroup (ZW), two- or single-transform batches (k_zpass / k_zpass_c1, round 4), and
+two wave-uniform branches inside the z pass (fp16 copy of the spectrum, fp32 dispersion array) -- from the tile size, the
+batch size, the pipeline depth, the mode and the precisions (ocean_api.hip: enqueue_frame, ocean_launch.h: launch_frame).  `ocean_last_launch` reports what a
 frame really launched.  This file
 
   * drives, per tile size with a z-pass code path of its own (64: two-transform batches; 256, 512: four-transform batches;
-    1024, 2048: two-transform batches + the two-column form when streamed; 4096: always two columns), every combination
+    1024: two-transform batches for a lone tile, single-transform batches for a batch, the two-column form when streamed;
+    2048: single-transform batches, the two-column form when streamed; 4096: always single-transform batches), every combination
     of store policy x intermediate precision x mode (FULL7 / JACOBIAN) x spectrum precision x dispersion width the
     launcher can select, checks tile 0 of each frame against the float64-FFT oracle, and asserts that the set of variants
     that met the oracle equals the set the launcher can select (a new variant without a test here fails);
@@ -128,19 +129,22 @@ def policies(n):
     big = max(1, (4096 * 4096) // (n * n))
     if n == 4096:
         return [("nts", 1, 1), ("stream", 1, 2)]
+    if n == 1024:       # (a batch of 1024^2 tiles with plain stores takes the single-transform z pass, a lone tile the two-transform one)
+        return [("plain", 1, 1), ("batch", 2, 1), ("nts", 1, 2), ("stream", big, 2)]
     return [("plain", 1, 1), ("nts", 1, 2), ("stream", big, 2)]
 
 
 def expected_variants(n):
     from watersurfacerendering_amd import _abi as A
     out = set()
-    two_col_capable = n >= 1024
-    for (name, _, _), z16, jac, h16, w32 in itertools.product(policies(n), (False, True), (False, True), (False, True), (False, True)):
+    for (name, tiles, _), z16, jac, h16, w32 in itertools.product(policies(n), (False, True), (False, True), (False, True), (False, True)):
         common = (A.OCEAN_LAUNCH_HALF_INTER if z16 else 0) | (A.OCEAN_LAUNCH_JACOBIAN if jac else 0)
+        # ocean_kernels.h: zpass_c1_pays -- 4096^2 always; 2048^2 and batches of 1024^2 unless the intermediates are streamed
+        c1 = n == 4096 or (name != "stream" and (n == 2048 or (n == 1024 and tiles >= 2)))
         zf = common | (A.OCEAN_LAUNCH_NT_INTER if name == "stream" else 0) | (A.OCEAN_LAUNCH_FP16_SPECTRUM if h16 else 0) | \
-            (A.OCEAN_LAUNCH_FP32_DISPERSION if w32 else 0)
-        xf = common | (A.OCEAN_LAUNCH_NT_MAPS if name != "plain" else 0)
-        zw = 2 if two_col_capable and (n == 4096 or name == "stream") else 1
+            (A.OCEAN_LAUNCH_FP32_DISPERSION if w32 else 0) | (A.OCEAN_LAUNCH_SINGLE_TRANSFORM if c1 else 0)
+        xf = common | (A.OCEAN_LAUNCH_NT_MAPS if name not in ("plain", "batch") else 0)
+        zw = 2 if n in (1024, 2048) and name == "stream" else 1
         out.add((n, zf, zw, xf, xf))
     return out
 
@@ -171,7 +175,7 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
                 assert np.array_equal(same[0], d) and np.array_equal(same[1], q) and same[2] == h, what
     want = expected_variants(n)
     assert seen == want, {"never launched": sorted(want - seen), "launched but not expected": sorted(seen - want)}
-    assert split_seen == (n == 2048)        # 1025 columns on 768 resident workgroups: only 2048^2 has a partially filled last round
+    assert not split_seen                   # (rounds 2-3 split the last round of a serial 2048^2 z pass; the single-transform form replaced it)
     oracles.drop(n)
 
 
@@ -185,7 +189,8 @@ def test_jacobian_mode_in_the_streamed_regimes(n, tiles, depth, bits, oracles):
     from watersurfacerendering_amd import _abi as A
     d, q, h, launches = run_frame(n, tiles, depth, True, bits, 32, 200.0)
     z, xb, xd = launches
-    assert z["per_workgroup"] == 2 or depth == 1 and n < 4096
+    assert z["per_workgroup"] == (2 if n < 4096 and depth == 2 else 1)
+    assert bool(z["flags"] & A.OCEAN_LAUNCH_SINGLE_TRANSFORM) == (n == 4096 or depth == 1)
     assert bool(z["flags"] & A.OCEAN_LAUNCH_NT_INTER) == (depth == 2)
     assert z["flags"] & A.OCEAN_LAUNCH_JACOBIAN and xb["flags"] & A.OCEAN_LAUNCH_JACOBIAN and xd["flags"] & A.OCEAN_LAUNCH_JACOBIAN
     check_against_oracle(d, q, h, oracles.frame(n, 200.0, True), True, TOL16 if bits == 16 else TOL, (n, tiles, depth, bits))

@@ -48,8 +48,13 @@ def _sha():
 
 
 def kernel_of(full):
+    """(launch name, tile size) of a rocprofv3 kernel name.  The z pass has several kernel forms (k_zpass, k_zpass_c1: ocean_kernels.h);
+    all of them are the frame's first launch, "k_zpass" in ocean_kernel_name's and bench.py's accounting."""
     m = re.search(r"(k_[a-z_0-9]+)<(\d+)", full)
-    return (m.group(1), int(m.group(2))) if m else (None, None)
+    if not m:
+        return (None, None)
+    name = m.group(1)
+    return ("k_zpass" if name.startswith("k_zpass") else name, int(m.group(2)))
 
 
 def stats(path, tiles=1):

@@ -31,7 +31,6 @@ struct ocean_ctx {
     int last_set = 0;
     int cu_count = 0;               // compute units of the device
     uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
-    uint32_t pers_n = 0, pers_slots = 0;   // persistent z pass: workgroups the device keeps resident (all CUs), and the tile size that was asked for
     bool lambda_uniform = true;
     bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)
 

@@ -168,8 +168,7 @@ struct FrameArgs {
     const float* lambda;     // [tiles], or null: every tile uses lambda_all
     float lambda_all;
     float t;
-    int zfull;               // z pass: workgroups [0, zfull) transform a whole spectrum column; the columns beyond are split over two
-                             //   workgroups each (one per batch of transforms) -- see k_zpass
+    int zfull;               // (unused since round 4: the split last round of the z pass is gone)
     int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only),
                              // 3 JACOBIAN (FULL7 + the cross derivative; displacement.w = Jacobian of the horizontal displacement)
 };
@@ -468,40 +467,6 @@ __device__ __forceinline__ void animate_with_mirror(float2 h0a, float2 h0b, floa
     bv = height_re(h0b.x, h0b.y, c, s);
 }
 
-// ---- phase 1 in two halves, for the persistent z pass (k_zpass<..., PERS>) ---------------------------------------------------------
-// A persistent workgroup works through several spectrum columns; the raw loads of column k+1 (ZRaw: nine registers per element pair in the
-// usual form of the spectrum -- fp32 h0, 16-bit dispersion) are ISSUED before the transforms of column k and CONSUMED after them, so the
-// load burst of a column travels under the previous column's butterflies, exchanges and stores instead of in front of its own.  Nothing
-// but the loads happens in zpass_load_raw -- any arithmetic on a loaded value would make the wave wait for it there --, and
-// zpass_animate_raw does exactly what zpass_load_pair + animate_with_mirror do, operation for operation: frames are bit-identical.
-struct ZRaw {
-    float4 ha;            // a(n), a(n+1): elements n, n+1 of column nb
-    float2 hb0, hb1;      // b(N-n), b(N-n-1): their point mirrors in column (N-nb)%N
-    unsigned wq;          // the two 16-bit multiples of the base frequency (elements n, n+1)
-};
-template <int N>
-__device__ __forceinline__ void zpass_load_raw(const FrameArgs& a, int tile, int col, int n, ZRaw& r)
-{
-    const size_t n2 = (size_t)N * N;
-    const int mcol = (N - col) & (N - 1);
-    const size_t g = (size_t)col * N + n;
-    const size_t m0 = (size_t)mcol * N + ((N - n) & (N - 1)), m1 = (size_t)mcol * N + (N - n - 1);
-    const float2* __restrict__ h0 = a.h0 + tile * n2;
-    r.ha = *reinterpret_cast<const float4*>(h0 + g);
-    r.hb0 = h0[m0]; r.hb1 = h0[m1];
-    r.wq = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
-}
-// S+ (a0 + b0)/2, (a1 + b1)/2 of the pair, or (a0, a1) for the Nyquist column; *sm = S-(n) = (a0 - b0)/2
-__device__ __forceinline__ float2 zpass_animate_raw(const ZRaw& r, float base, float t, bool col0, float* sm)
-{
-    const float w0 = mul_nocontract((float)(r.wq & 0xffffu), base), w1 = mul_nocontract((float)(r.wq >> 16), base);
-    float a0, b0, a1, b1;
-    animate_with_mirror(make_float2(r.ha.x, r.ha.y), r.hb0, w0, t, a0, b0);
-    animate_with_mirror(make_float2(r.ha.z, r.ha.w), r.hb1, w1, t, a1, b1);
-    *sm = 0.5f * (a0 - b0);
-    return col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
-}
-
 // ---- half-spectrum storage geometry -------------------------------------------
 #ifndef OCEAN_ZTILE
 #define OCEAN_ZTILE 8          // rows per block of the intermediates (fp32: 64-byte pieces)
@@ -631,7 +596,7 @@ template <int N> constexpr int zpass_columns() { return (OCEAN_ZC4 && (N == 512 
 // The launcher picks (k_zpass<..., ZW>): always at 4096^2 (one workgroup per CU either way: z pass 150 -> 132 us), from 1024 up
 // whenever the intermediates are streamed; never for a single small tile, whose few, longer workgroups would leave the chip
 // emptier (1024^2 z pass 16.0 -> 18.4 us).
-template <int N> constexpr bool zpass_has_width2() { return zpass_columns<N>() == 2 && N >= 1024; }
+template <int N> constexpr bool zpass_has_width2() { return zpass_columns<N>() == 2 && N >= 1024 && N <= 2048; }
 
 // The first-stage input of one z-axis transform at element e of a spectrum column: pair 0 (uz Tz, -ux Tx), pair 1
 // (-kz Tz, kx Tx), pair 2 (kx ux S+, kz uz S+), pair 3 (S+, g3 kx uz Tc).  ONE definition with contraction off, so that every
@@ -649,15 +614,10 @@ __device__ __forceinline__ c32 zpass_input(float kx, float kx2, float kz, float 
     else return make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
 }
 
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `hook` runs once per thread, with the first output of the LAST stage of the column's last batch: where the persistent z pass issues
-// the next column's loads -- the radix-4 last stage holds four complex values at a time, the stages before it sixteen and a twiddle
-// chain, so the nine registers per element pair in flight fit there without costing the kernel a workgroup per CU.
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC, class Hook = NoHook>
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
                                                  TwiddleRegs<N, ZC, T, P>& twr, float kx, float sm0, int tid,
-                                                 int tile, int nb, int batches /* bit 0: {pair 0, pair 1}, bit 1: {pair 2, height} */,
-                                                 Hook hook = Hook())
+                                                 int tile, int nb, int batches /* bit 0: {pair 0, pair 1}, bit 1: {pair 2, height} */)
 {
     using HF = Half<N>;
     const float kx2 = kx * kx;
@@ -779,7 +739,6 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
-            if (u == 0 && i == 0) hook();
             if (c) {
                 if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
                 else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
@@ -804,7 +763,6 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     c32* fbuf = reinterpret_cast<c32*>(smem);
     float* sp0 = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());   // S+ of column nb0, of column nb0 + 1
     float* sp1 = sp0 + N;
-    float* kzt = sp1 + N;
     float* raw = reinterpret_cast<float*>(fbuf);                           // [0], [1]: S-(0) of the two columns, until the first exchange
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
@@ -833,11 +791,17 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
                 animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
                 *reinterpret_cast<float2*>((c ? sp1 : sp0) + n) = make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
-                if (c == 0) *reinterpret_cast<float2*>(kzt + n) = *reinterpret_cast<const float2*>(k1 + n);
                 if (n == 0) raw[c] = 0.5f * (a0 - b0);
             }
         }
     });
+    // kz of this thread's first-stage inputs: elements j + i * (N / R0) in every one of the four batches, whichever column the thread's
+    // transform belongs to -- in registers (from the k table, once per workgroup) instead of an LDS table: N floats less LDS (2048: 51
+    // instead of 59 KB, three workgroups per CU instead of two) and a third of the first stages' LDS reads
+    static_assert(FirstStage<N, 2, T, P>::IT == 1, "one first-stage butterfly per thread");
+    float kzr[P::r[0]];
+#pragma unroll
+    for (int i = 0; i < P::r[0]; ++i) kzr[i] = k1[tid / 2 + i * (N / P::r[0])];
     __syncthreads();
     const float sm00 = raw[0], sm01 = raw[1];      // S-(0) of the two columns
 
@@ -863,123 +827,41 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     };
     if (a.mode != 2) {
         {   // pair 0: (uz Tz, -ux Tx)
-            auto in = [&](int e, int c, int, int) -> c32 {
+            auto in = [&](int e, int c, int, int i) -> c32 {
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
-                return zpass_input<0>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
+                return zpass_input<0>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
         {   // pair 1: (-kz Tz, kx Tx)
-            auto in = [&](int e, int c, int, int) -> c32 {
+            auto in = [&](int e, int c, int, int i) -> c32 {
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
-                return zpass_input<1>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
+                return zpass_input<1>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
     }
     if (a.mode == 0 || a.mode == 3) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
-        auto in = [&](int e, int c, int, int) -> c32 {
+        auto in = [&](int e, int c, int, int i) -> c32 {
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
-            return zpass_input<2>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, false, 1.0f);
+            return zpass_input<2>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
         };
         auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
     {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
-        auto in = [&](int e, int c, int, int) -> c32 {
+        auto in = [&](int e, int c, int, int i) -> c32 {
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
             if (!jac) return make_float2(sv, 0.0f);
-            return zpass_input<3>(kx, kx2, kzt[e], sv, sv, tz, tz, 1.0f, true, g3);
+            return zpass_input<3>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, true, g3);
         };
         auto out = [&](int p, int c, c32 v, int u, int i) {
             if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb0 + c, p, u, i), v, s3);
             else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb0 + c, p, u, i), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
-    }
-}
-
-// Persistent form of the one-column z pass (k_zpass<..., PERS = true>): the grid is the number of workgroups the device keeps resident, and
-// a workgroup works through the columns job, job + gridDim.x, ... of its tile.  The raw spectrum loads of its NEXT column are issued
-// before the transforms of the current one (zpass_load_raw / zpass_animate_raw), the kz table and the twiddles are set up once, and no
-// column is animated twice (the split last round of the one-shot form animates 257 columns of a serial 2048^2 frame twice).
-// Barriers: the S+ table of column k+1 is written after the transforms of column k -- every wave is past the last first stage that reads
-// it, because two stage barriers follow that stage --, and S-(0) lives outside the FFT image, which the slower waves may still be reading.
-template <int N, int T, class P, bool ZNT, bool Z16>
-__device__ __forceinline__ void zpass_persistent(const FrameArgs& a, unsigned char* smem, TwiddleRegs<N, 2, T, P>& twr, const int tid0, int tile)
-{
-    static_assert(zpass_columns<N>() == 2, "two-transform batches");
-    constexpr int NC = N / 2 + 1;                       // columns 0 .. N/2
-    constexpr int PAIRS = N / 2, P1 = PAIRS / T;
-    static_assert(PAIRS % T == 0 && P1 >= 1 && P1 <= 2, "prefetch registers per thread");
-    c32* fbuf = reinterpret_cast<c32*>(smem);
-    float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 2>());
-    float* kzt = sp + N;
-    float* sm = kzt + N;                                // [0]: S-(0) of the current column
-    const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
-    const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
-    const float base = a.base_freq[tile];
-    int job = (int)blockIdx.x;
-    ZRaw r[P1];
-    {
-        const int nb0 = xcd_swizzle(job, NC);           // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
-#pragma unroll
-        for (int u = 0; u < P1; ++u) zpass_load_raw<N>(a, tile, nb0, 2 * (tid0 + u * T), r[u]);
-#pragma unroll
-        for (int u = 0; u < P1; ++u) {
-            const int n = 2 * (tid0 + u * T);
-            *reinterpret_cast<float2*>(kzt + n) = *reinterpret_cast<const float2*>(k1 + n);
-        }
-    }
-    if (blockIdx.x == 0 && tid0 == 0) {
-        // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
-        a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
-        a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
-    }
-    // one column: S+ from the registers, barrier, the four transforms; the next column's loads are issued from inside the last stage
-    auto column = [&](auto col0_tag, const int nb, const int nb_next, const bool has_next) {
-        constexpr bool COL0 = decltype(col0_tag)::value;
-        // (the thread index is laundered once per column: everything derived from it -- load offsets, LDS addresses, the store bases of
-        //  the last stages -- is then recomputed per column, a few instructions, instead of being hoisted out of the loop into
-        //  registers that would cost the third workgroup per CU)
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
-#pragma unroll
-        for (int u = 0; u < P1; ++u) {
-            const int n = 2 * (tid + u * T);
-            float smv;
-            *reinterpret_cast<float2*>(sp + n) = zpass_animate_raw(r[u], base, t, COL0, &smv);
-            if (n == 0) sm[0] = smv;
-        }
-        __syncthreads();
-        const float sm0 = sm[0];
-        auto prefetch = [&]() {
-#ifndef OCEAN_PERS_BRANCH
-            (void)has_next;         // (the last column of a workgroup loads some column once more, unused: cheaper than a branch around the loads)
-#else
-            if (has_next)
-#endif
-            {
-#pragma unroll
-                for (int u = 0; u < P1; ++u) zpass_load_raw<N>(a, tile, nb_next, 2 * (tid + u * T), r[u]);
-            }
-        };
-        zpass_transforms<N, T, P, COL0, ZNT, Z16, 2>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, 3, prefetch);
-    };
-    // the Nyquist column 0 (xcd_swizzle(0, .) == 0: workgroup 0's first job) has a code path of its own; it stays outside the loop
-    if (job == 0) {
-        const int next = (int)gridDim.x;
-        column(std::true_type{}, 0, next < NC ? xcd_swizzle(next, NC) : 0, next < NC);
-        job = next;
-        if (job >= NC) return;
-    }
-    for (;;) {
-        const int next = job + (int)gridDim.x;
-        column(std::false_type{}, xcd_swizzle(job, NC), next < NC ? xcd_swizzle(next, NC) : 0, next < NC);
-        if (next >= NC) break;
-        job = next;
     }
 }
 
@@ -1000,23 +882,15 @@ __device__ __forceinline__ void zpass_persistent(const FrameArgs& a, unsigned ch
 // minimum waves per SIMD asked of the register allocator: three 512-thread workgroups per CU at 2048 (since round 3 the kernel
 // needs 62 VGPRs and would fit four, but its 51 KB of LDS allow three); 1024 and 4096 keep the looser bound
 template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 1024 ? 3 : 1); }
-// (two columns per workgroup at 2048: 59 KB of LDS allow two workgroups per CU, i.e. four waves per SIMD and 128 VGPRs; the
-//  80-VGPR cap of the one-column form would only make that variant spill)
+// (two columns per workgroup: since round 4 its kz live in registers, the LDS footprint is the one-column form's and so is the bound)
 #ifndef OCEAN_ZLB
-#define OCEAN_ZLB ((ZW == 2 && N == 2048) ? 4 : zpass_min_waves<N>())
+#define OCEAN_ZLB zpass_min_waves<N>()
 #endif
-template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true, bool PERS = false>
+template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true>
 __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ZC = zpass_columns<N>();
-    if constexpr (PERS) {
-        static_assert(ZW == 1 && FAST, "the persistent form exists for the usual form of the spectrum, one column at a time");
-        TwiddleRegs<N, 2, T, P> twp;
-        twp.load(a.tw, threadIdx.x);
-        zpass_persistent<N, T, P, ZNT, Z16>(a, smem, twp, threadIdx.x, blockIdx.y);
-        return;
-    }
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // ZC interleaved transforms
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, ZC>());   // S+ [N]
     float* kzt = sp + N;                                                   // kz table [N]
@@ -1024,9 +898,9 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
-    // Serial frames of a tile whose columns do not fill the chip in whole rounds (2048^2: 1025 columns on 768 resident
-    // workgroups) end with a round of lone workgroups, each a long dependent chain: the host then splits the columns of
-    // that last round over two workgroups each, one per batch of transforms (both animate the column; a.zfull < N/2+1).
+    // (Rounds 2-3 split the columns of a partially filled last round of a serial 2048^2 frame -- 1025 columns on 768 resident
+    //  workgroups -- over two workgroups each, one per batch, both animating the column; since round 4 that tile size runs the
+    //  single-transform form, k_zpass_c1, whose 1025 smaller workgroups are resident at once.)
     static_assert(ZW == 1 || zpass_has_width2<N>(), "two columns per workgroup: two-batch sizes from 1024 up");
     TwiddleRegs<N, ZC, T, P> twr;
     twr.load(a.tw, tid);
@@ -1099,16 +973,168 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
         __syncthreads();            // the slowest wave is done with the FFT image before the next column's h~ overwrites it
         one_column(1, 3);
     } else {
-        int nb = (int)blockIdx.x, batches = 3;
-        if (ZC == 2 && nb >= a.zfull) { const int r = nb - a.zfull; nb = a.zfull + (r >> 1); batches = 1 + (r & 1); }
+        int nb = (int)blockIdx.x;
+        const int batches = 3;
 #if OCEAN_ZTILE
-        else nb = xcd_swizzle(nb, a.zfull);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
+        nb = xcd_swizzle(nb, (int)gridDim.x);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
 #endif
         one_column(nb, batches);
     }
-#ifdef OCEAN_EXP_ENDWAIT      // experiment: the workgroup stays until its stores have been taken (what a persistent workgroup's next column waits for)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+}
+
+// ============================================================================
+// k_zpass_c1: the z pass with ONE transform per batch (four batches per column: pair 0, pair 1, pair 2, height) and half the threads.
+// For 4096^2: the two-transform forms need 102-119 KB of LDS (70 KB of FFT image + the S+ / kz tables) -- ONE 1024-thread workgroup per
+// CU, whose load burst, butterflies, exchanges and stores run strictly one after the other (0.43 of peak, the phases of a
+// lone workgroup never overlap).  With one transform in the image the workgroup needs 35 + 32 = 67 KB and 512 threads: TWO independent
+// workgroups per CU, the same number of waves, and each one's load burst and store tail travel under the other's transforms.  Same radix
+// plan, same inputs (zpass_input), same twiddles: bit-identical to the other forms (tests/test_variants_gpu.py).
+// ============================================================================
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16>
+__device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float (&kzr)[P::r[0]],
+                                                        TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb)
+{
+    using HF = Half<N>;
+    // kz of the first stage's inputs: thread j reads elements j + i * (N / R0), i = 0 .. R0-1, in every one of the four batches -- the
+    // same R0 wave-vector components each time, so they live in registers (kzr[i], fetched once per workgroup from the k table) instead
+    // of an LDS table: 16 KB less LDS at 4096 -- three workgroups per CU instead of two -- and a quarter of the first stages' LDS reads.
+    static_assert(FirstStage<N, 1, T, P>::IT == 1, "one first-stage butterfly per thread");
+    const float kx2 = kx * kx;
+    [[maybe_unused]] float su = 1.0f, sk = 1.0f, s3 = 1.0f;
+    float g3 = 1.0f;
+    if constexpr (Z16) { const float4 zs = a.zscale[2 * tile]; su = zs.x; sk = zs.y; s3 = a.zscale[2 * tile + 1].x; }
+    if (a.mode == 3) g3 = a.zscale[2 * tile + 1].y;
+    constexpr size_t ES = Z16 ? 4 : 8;
+    float2* __restrict__ zt = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z) + (size_t)tile * HF::Z_TILE * ES);
+    float2* __restrict__ z3 = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.z3) + (size_t)tile * HF::Z_GROUP * ES);
+    float2* __restrict__ zh = reinterpret_cast<float2*>(reinterpret_cast<char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
+    const bool jac = a.mode == 3;
+    ZStore<N, T, P, 1, Z16> zo;
+    zo.init(tid, nb);
+    // S+(e), Tx(e), Tz(e), Tc(e) (see k_zpass: the Nyquist column carries G(e) = h~(e, 0) and forms S+- on the fly)
+    auto fetch = [&](int e, float& sv, float& tx, float& tz, float& tc) {
+        if constexpr (COL0) {
+            const float g1 = sp[e], g2 = sp[(N - e) & (N - 1)];
+            sv = 0.5f * (g1 + g2);
+            tx = 0.5f * (g1 - g2);
+            tz = (e == 0) ? tx : sv;
+            tc = (e == 0) ? sv : tx;
+        } else {
+            sv = sp[e];
+            tx = sv;
+            tz = (e == 0) ? sm0 : sv;
+            tc = tz;
+        }
+    };
+    if (a.mode != 2) {
+        {   // pair 0: (uz Tz, -ux Tx)
+            auto in = [&](int e, int, int, int i) -> c32 {
+                float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
+                return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
+            };
+            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb, p, u, i), v, su); };
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+        }
+        {   // pair 1: (-kz Tz, kx Tx)
+            auto in = [&](int e, int, int, int i) -> c32 {
+                float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
+                return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
+            };
+            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+        }
+    }
+    if (a.mode == 0 || a.mode == 3) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
+        auto in = [&](int e, int, int, int i) -> c32 {
+            float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
+            return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
+        };
+        auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+    }
+    {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
+        auto in = [&](int e, int, int, int i) -> c32 {
+            float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
+            if (!jac) return make_float2(sv, 0.0f);
+            return zpass_input<3>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, true, g3);
+        };
+        auto out = [&](int p, int, c32 v, int u, int i) {
+            if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
+            else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
+        };
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+    }
+}
+
+template <int N> constexpr size_t zpass_c1_lds_bytes() { return sizeof(c32) * fft_lds_elems<N, 1>() + sizeof(float) * N; }
+
+template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true>
+__global__ void __launch_bounds__(T, 6) k_zpass_c1(const FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* fbuf = reinterpret_cast<c32*>(smem);                              // one transform
+    float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 1>());    // S+ [N]
+    float* raw = reinterpret_cast<float*>(fbuf);                           // [0]: S-(0) of the column, until the first exchange
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.y;
+    TwiddleRegs<N, 1, T, P> twr;
+    twr.load(a.tw, tid);
+    const int nb = xcd_swizzle((int)blockIdx.x, N / 2 + 1);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
+    const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
+    const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
+    const bool col0 = (nb == 0);
+    const float h16s = a.h0h ? a.h0_inv_scale[tile] : 1.0f;
+    const float base = a.omega_q ? a.base_freq[tile] : 0.0f;
+    // phase 1 exactly as in k_zpass (zpass_load_pair / animate_with_mirror)
+    spectrum_form<FAST>(a, [&](auto h16, auto w16) {
+        constexpr bool H16 = decltype(h16)::value, W16 = decltype(w16)::value;
+        constexpr int PAIRS = N / 2;
+        constexpr int P1 = (PAIRS + T - 1) / T;
+        constexpr int PB = P1 > 4 ? 4 : P1;          // items in flight per thread
+        static_assert(P1 % PB == 0 && PAIRS % T == 0, "phase-1 batches");
+#pragma unroll 1
+        for (int ub = 0; ub < P1; ub += PB) {
+            float4 ha[PB];
+            float2 hb0[PB], hb1[PB], wv[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+                zpass_load_pair<N, H16, W16>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int n = 2 * (tid + (ub + u) * T);
+                float a0, b0, a1, b1;
+                animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
+                animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
+                *reinterpret_cast<float2*>(sp + n) = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
+                if (n == 0) raw[0] = 0.5f * (a0 - b0);          // S-(0), for everybody (the FFT image is not in use yet)
+            }
+        }
+    });
+    if (blockIdx.x == 0 && tid == 0) {
+        // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
+        a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
+        a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
+    }
+    float kzr[P::r[0]];                                   // kz of this thread's first-stage inputs (behind phase 1: the registers are free by now)
+#pragma unroll
+    for (int i = 0; i < P::r[0]; ++i) kzr[i] = k1[tid + i * (N / P::r[0])];
+    __syncthreads();
+    const float sm0 = raw[0];
+    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_single_transforms<N, T, P, false, ZNT, Z16>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+}
+// tile sizes whose z pass has the single-transform form (the launcher picks it where it is faster: ocean_launch.h)
+template <int N> constexpr bool zpass_has_c1() { return N >= 1024; }
+template <int N> constexpr int zpass_c1_threads() { return N / 8; }          // one radix-8 butterfly per thread and stage
+// Where the single-transform form is the faster one (profiles/r04_zpass_experiments.txt; stream_maps: ocean_ctx.h, bit 2 = streamed
+// intermediates): 4096^2 always (three workgroups per CU instead of one: z pass 111 -> 95 us); 2048^2 and batches of 1024^2 with plain
+// intermediate stores (2048^2 24.4 -> 23.2 us and no split last round, 8 x 1024^2 38.1 -> 33.9); a lone 1024^2 tile keeps the
+// two-transform form (half the dependent chain: 14.3 vs 15.2 us), streamed intermediates below 4096 the two-column form (whole-line stores).
+template <int N> inline bool zpass_c1_pays(int stream_maps, unsigned tiles)
+{
+    if (N == 4096) return true;
+    if (stream_maps & 4) return false;
+    return N == 2048 || tiles >= 2;
 }
 
 // resident z-pass workgroups per CU (lower bound from LDS, threads and the register cap of the launch bounds)
@@ -1123,13 +1149,10 @@ template <int N, int T> constexpr int zpass_blocks_per_cu()
 
 template <int N, int ZW = 1> constexpr size_t zpass_lds_bytes()
 {
-    return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * (1 + ZW) * N;
+    // FFT image + two tables of N floats: S+ and kz of one column, or S+ of both columns of the two-column form (whose kz live in registers)
+    return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * 2 * N;
 }
-// the persistent form keeps S-(0) outside the FFT image
-template <int N> constexpr size_t zpass_lds_bytes_persistent() { return zpass_lds_bytes<N, 1>() + 16; }
-template <int N> constexpr bool zpass_has_persistent() { return zpass_columns<N>() == 2 && N >= 1024; }
-// where the launcher picks it (stream_maps: ocean_ctx.h; bit 4 = the frame has the device to itself)
-template <int N> inline bool zpass_persistent_pays(int stream_maps, unsigned tiles) { (void)stream_maps; (void)tiles; return false; }
+
 
 // ---- x-pass helpers ------------------------------------------------------------------
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the

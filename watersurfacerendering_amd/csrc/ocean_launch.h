@@ -43,18 +43,25 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr unsigned hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
+    // Which forms of the z pass a tile size has (ocean_kernels.h).  ZW1: one column, two-transform batches (four-transform batches at 256 /
+    // 512) -- every size below 1024 and a single 1024^2 tile; C1: one column, single-transform batches, half the threads -- 4096^2
+    // always, 2048^2 and batches of 1024^2 unless the intermediates are streamed; ZW2: two neighbouring columns (whole-line stores) --
+    // streamed intermediates at 1024^2 and 2048^2.  Developer builds keep every form for A/B runs (OCEAN_ZW, OCEAN_ZC1).
+#ifdef OCEAN_DEVELOPER
+    constexpr bool DEV = true;
+#else
+    constexpr bool DEV = false;
+#endif
+    constexpr bool HAS1 = DEV || N <= 1024;
+    constexpr bool HASC1 = zpass_has_c1<N>();
+    constexpr bool HAS2_PLAIN = DEV && HAS2;              // (the two-column form with plain stores: never selected by the shipped rules)
     if (c->attr_n != (uint32_t)N) {
-#define OCEAN_ALLOW_Z(znt, z16, fast) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, lds_rows)) != hipSuccess) return e; \
-        if constexpr (HAS2 && (znt || N == 4096)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, lds_rows2)) != hipSuccess) return e;
+#define OCEAN_ALLOW_Z(znt, z16, fast) \
+        if constexpr (HAS1) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, lds_rows)) != hipSuccess) return e; \
+        if constexpr (HAS2 && (znt || HAS2_PLAIN)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, lds_rows2)) != hipSuccess) return e; \
+        if constexpr (HASC1) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e;
 #define OCEAN_ALLOW_Z2(fast) OCEAN_ALLOW_Z(false, false, fast) OCEAN_ALLOW_Z(true, false, fast) OCEAN_ALLOW_Z(false, true, fast) OCEAN_ALLOW_Z(true, true, fast)
         OCEAN_ALLOW_Z2(true) OCEAN_ALLOW_Z2(false)
-        if constexpr (zpass_has_persistent<N>()) {
-            constexpr size_t lp = zpass_lds_bytes_persistent<N>();
-            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, false, 1, true, true>, lp)) != hipSuccess) return e;
-            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, false, 1, true, true>, lp)) != hipSuccess) return e;
-            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, false, true, 1, true, true>, lp)) != hipSuccess) return e;
-            if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, true, true, 1, true, true>, lp)) != hipSuccess) return e;
-        }
 #undef OCEAN_ALLOW_Z2
 #undef OCEAN_ALLOW_Z
 #define OCEAN_ALLOW_X(kern, lds) \
@@ -82,92 +89,50 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     arm(0);
 #endif
     {
-        // two neighbouring columns per workgroup (k_zpass<..., 2>): 4096^2 always, from 1024 up when the intermediates are streamed
-        bool zw2 = HAS2 && (N == 4096 || (stream_maps & 4));
+        // the form of the z pass (see above); the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the
+        // other forms' code (FAST)
+        const bool fast = !a.h0h && a.omega_q;
+        bool c1 = HASC1 && zpass_c1_pays<N>(stream_maps, tiles);
+        bool zw2 = HAS2 && !c1 && (stream_maps & 4);
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
+        static const char* const c1_env = getenv("OCEAN_ZC1");                  // 0 / 1
+        if (c1_env && HASC1) c1 = atoi(c1_env) != 0;
+        zw2 = HAS2 && !c1 && (stream_maps & 4);
         static const char* const zw_env = getenv("OCEAN_ZW");                   // 1 or 2
-        if (zw_env && HAS2) zw2 = atoi(zw_env) == 2 && (N == 4096 || (stream_maps & 4));
+        if (zw_env && HAS2 && !c1) zw2 = atoi(zw_env) == 2;
 #endif
         unsigned gx = zw2 ? N / 4 + 1 : N / 2 + 1;
         FrameArgs za = a;
         za.zfull = (int)gx;
-        bool split = false;
-        // the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the other forms' code (FAST)
-        const bool fast = !a.h0h && a.omega_q;
-        // persistent one-column form: as many workgroups as stay resident, each working through its share of the columns with the next
-        // column's loads in flight under the current column's transforms
-        bool pers = false;
-        if constexpr (zpass_has_persistent<N>()) {
-            pers = fast && !zw2 && zpass_persistent_pays<N>(stream_maps, tiles);
-#ifdef OCEAN_DEVELOPER
-            static const char* const pers_env = getenv("OCEAN_ZPERS");            // 0 / 1
-            if (pers_env) pers = fast && !zw2 && atoi(pers_env) != 0;
-#endif
-        }
-        if (pers) {
-            if constexpr (zpass_has_persistent<N>()) {
-                if (c->pers_n != (uint32_t)N) {         // resident workgroups per CU of the persistent kernel, asked of the runtime once per tile size
-                    int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_zpass<N, G::T_ROWS, typename G::PR, false, false, 1, true, true>,
-                                                                     G::T_ROWS, zpass_lds_bytes_persistent<N>()) != hipSuccess || per_cu < 1)
-                        per_cu = zpass_blocks_per_cu<N, G::T_ROWS>();
-                    c->pers_slots = (uint32_t)per_cu * (uint32_t)c->cu_count;
-                    c->pers_n = (uint32_t)N;
-                }
-            }
-            unsigned slots = c->pers_slots;
-#ifdef OCEAN_DEVELOPER
-            static const char* const pg_env = getenv("OCEAN_ZPERS_GRID");          // resident workgroups assumed, all tiles together
-            if (pg_env) slots = (unsigned)atoi(pg_env);
-#endif
-            unsigned per_tile = slots / tiles;
-            if (per_tile < 1) per_tile = 1;
-            if (per_tile < gx) gx = per_tile;
-        } else
-        if ((stream_maps & 16) && tiles == 1 && zpass_columns<N>() == 2 && !zw2) {
-            // serial frames: split the columns of the last, partially filled round over two workgroups each
-            const unsigned slots = (unsigned)zpass_blocks_per_cu<N, G::T_ROWS>() * (unsigned)c->cu_count;
-            const unsigned rest = gx % slots;
-            if (gx > slots && rest != 0 && 2 * rest <= slots) { za.zfull = (int)(gx - rest); gx = (gx - rest) + 2 * rest; split = true; }
-        }
 #if defined(OCEAN_STAMPS) || defined(OCEAN_DEVELOPER)
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
 #endif
-        const dim3 grid(gx, tiles), block(G::T_ROWS);
+        const unsigned threads = c1 ? (unsigned)zpass_c1_threads<N>() : (unsigned)G::T_ROWS;
+        const size_t lds = c1 ? zpass_c1_lds_bytes<N>() : (zw2 ? lds_rows2 : lds_rows);
+        const dim3 grid(gx, tiles), block(threads);
         {
             ocean_launch_info& li = c->last_launch[0];
-            li.tile_size = N; li.grid_x = gx; li.grid_y = tiles; li.block = G::T_ROWS; li.mode = (uint32_t)a.mode;
+            li.tile_size = N; li.grid_x = gx; li.grid_y = tiles; li.block = threads; li.mode = (uint32_t)a.mode;
             li.per_workgroup = zw2 ? 2u : 1u;
-            li.lds_bytes = (uint32_t)(zw2 ? lds_rows2 : lds_rows);
+            li.lds_bytes = (uint32_t)lds;
             li.flags = ((stream_maps & 4) ? OCEAN_LAUNCH_NT_INTER : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
                        (a.mode == 3 ? OCEAN_LAUNCH_JACOBIAN : 0u) | (a.h0h ? OCEAN_LAUNCH_FP16_SPECTRUM : 0u) |
-                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (split ? OCEAN_LAUNCH_SPLIT_LAST_ROUND : 0u) |
-                       (pers ? OCEAN_LAUNCH_PERSISTENT : 0u);
-            if (pers) li.lds_bytes = (uint32_t)zpass_lds_bytes_persistent<N>();
+                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (c1 ? OCEAN_LAUNCH_SINGLE_TRANSFORM : 0u);
         }
-        if constexpr (zpass_has_persistent<N>()) {
-            if (pers) {
-                constexpr size_t lp = zpass_lds_bytes_persistent<N>();
-                const int v = ((stream_maps & 4) ? 1 : 0) | ((stream_maps & 8) ? 2 : 0);
-                if (v == 0) launch(k_zpass<N, G::T_ROWS, typename G::PR, false, false, 1, true, true>, grid, block, lp, st, marks, za);
-                else if (v == 1) launch(k_zpass<N, G::T_ROWS, typename G::PR, true, false, 1, true, true>, grid, block, lp, st, marks, za);
-                else if (v == 2) launch(k_zpass<N, G::T_ROWS, typename G::PR, false, true, 1, true, true>, grid, block, lp, st, marks, za);
-                else launch(k_zpass<N, G::T_ROWS, typename G::PR, true, true, 1, true, true>, grid, block, lp, st, marks, za);
-            }
-        }
-        if (!pers) {
+        bool launched = false;
 #define OCEAN_ZPASS3(znt, z16, fast) \
-        do { if constexpr (HAS2 && (znt || N == 4096)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds_rows2, st, marks, za); break; } } \
-             launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds_rows, st, marks, za); } while (0)
+        do { if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, grid, block, lds, st, marks, za); launched = true; break; } } \
+             if constexpr (HAS2 && (znt || HAS2_PLAIN)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds, st, marks, za); launched = true; break; } } \
+             if constexpr (HAS1) { if (!c1 && !zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds, st, marks, za); launched = true; } } } while (0)
 #define OCEAN_ZPASS2(znt, z16) \
         do { if (fast) OCEAN_ZPASS3(znt, z16, true); else OCEAN_ZPASS3(znt, z16, false); } while (0)
 #define OCEAN_ZPASS(znt) \
         do { if (stream_maps & 8) OCEAN_ZPASS2(znt, true); else OCEAN_ZPASS2(znt, false); } while (0)
         if (stream_maps & 4) OCEAN_ZPASS(true); else OCEAN_ZPASS(false);
-        }
 #undef OCEAN_ZPASS
 #undef OCEAN_ZPASS2
 #undef OCEAN_ZPASS3
+        if (!launched) return hipErrorInvalidConfiguration;     // (a form this build does not carry: the rules above never ask for one)
     }
 #ifdef OCEAN_STAMPS
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
