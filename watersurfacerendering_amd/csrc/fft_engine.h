@@ -237,6 +237,20 @@ __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >>
 // idx0 / 16 + d / 16 (checked exhaustively for every plan of this file: tools/check_lds_offsets.py).
 template <int C> constexpr int lds_delta(int d) { return (d + d / 16) * C; }
 
+// Row-major image of the LAST exchange of an LM = 1 batch (the x passes): element (idx, c) at c * lds_row<N>() + idx.  The last stage of
+// that layout reads 64 consecutive idx of ONE column per wave -- in the c-interleaved image those are 32 bytes apart, eight lanes per bank
+// pair: 4-way conflicts, a third of the x passes' LDS cycles (PMC, profiles/r03z_pmc_*) -- here they are 512 contiguous bytes.  The stage
+// before it writes 16 lanes = (16 / C) idx x C columns per pass, 128 / C contiguous bytes in each of C rows: conflict-free when the rows
+// start 32 / C banks apart (mod 32), i.e. lds_row = N + 16 / C float2.  In place like every exchange (all reads, barrier, all writes), so
+// changing the layout between two stages costs nothing.
+template <int N, int C> constexpr int lds_row() { return N + 16 / C; }
+template <int N, int C> __device__ __forceinline__ int lds_index_rm(int idx, int c) { return c * lds_row<N, C>() + idx; }
+// (only where the LM = 1 lane layout is in effect -- last_stage_map: whole waves per column -- and the rows fit the image's allocation)
+template <int N, int C, int LM, int RLAST> constexpr bool lds_row_major_last()
+{
+    return LM == 1 && C > 1 && 16 % C == 0 && ((N / RLAST) * C) % (64 * C) == 0 && C * lds_row<N, C>() <= fft_lds_elems<N, C>();
+}
+
 // Work-item -> (column c, butterfly j) of the LAST stage.  Two lane layouts for a batch whose
 // items fill whole waves:
 //   LM = 0  the 64 lanes of a wave cover 64/C consecutive j of EVERY column, so a store
@@ -305,9 +319,11 @@ template <int N, int C, int T, class P, int LM = 0> struct TwiddleRegs {
 //          serve values it prefetched into registers);  otherwise from LDS
 //   LAST : outputs to out(idx, c, value, u, i) (u, i are unrolled constants);
 //          otherwise to LDS, in place (reads complete -> barrier -> writes)
-template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, class TW, class In, class Out>
+template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, bool WRM, class TW, class In, class Out>
 __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
+    // WRM: this stage's outputs feed the last stage of a batch whose last exchange is row-major (lds_row_major_last)
+    constexpr bool RRM = LAST && !FIRST && lds_row_major_last<N, C, LM, R>();      // ... and the last stage reads that image
     [[maybe_unused]] constexpr int STAMP_BASE = STAGE;
     constexpr int ITEMS = (N / R) * C;
     constexpr int IT = (ITEMS + T - 1) / T;
@@ -327,10 +343,11 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
                 int c, j;
                 last_stage_map<N, C, R, LM>(w, c, j);
                 v2 x[R];
-                [[maybe_unused]] const int rb = lds_index<C>(j, c);
+                [[maybe_unused]] const int rb = RRM ? lds_index_rm<N, C>(j, c) : lds_index<C>(j, c);
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     if constexpr (FIRST) x[i] = tov(in(j + i * (N / R), c, u, i));
+                    else if constexpr (RRM) x[i] = ldsv[rb + i * (N / R)];
                     else x[i] = ldsv[rb + lds_delta<C>(i * (N / R))];
                 }
 #ifndef OCEAN_ABL_NOFFT
@@ -375,9 +392,9 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             const int c = w % C, j = w / C;
             const int k = j % NS;
             const int j0 = (j - k) * R + k;
-            const int wb = lds_index<C>(j0, c);
+            const int wb = WRM ? lds_index_rm<N, C>(j0, c) : lds_index<C>(j0, c);
 #pragma unroll
-            for (int i = 0; i < R; ++i) ldsv[wb + lds_delta<C>(i * NS)] = x[u][i];
+            for (int i = 0; i < R; ++i) ldsv[wb + (WRM ? i * NS : lds_delta<C>(i * NS))] = x[u][i];
         }
     }
 }
@@ -387,7 +404,8 @@ __device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In&
 {
     constexpr int R = P::r[STAGE];
     constexpr bool FIRST = STAGE == 0, LAST = STAGE == P::S - 1;
-    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM>(lds, twr, tid, in, out);
+    constexpr bool WRM = STAGE == P::S - 2 && lds_row_major_last<N, C, LM, P::last>();
+    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM, WRM>(lds, twr, tid, in, out);
     OCEAN_STAMP(10 + 3 * STAGE);
     if constexpr (!LAST) {
         __syncthreads();
