@@ -7,7 +7,7 @@ TAG=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for D in 1 3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_d$D -- python3 $R/bench.py --depth $D --no-cpu-baseline --no-extra --no-gather > $R/gpurun_out/prof_${TAG}_d$D.json 2> $R/gpurun_out/prof_${TAG}_d$D.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_d$D -- python3 $R/bench.py --depth $D --steps 600 --warmup 300 --no-cpu-baseline --no-extra --no-gather > $R/gpurun_out/prof_${TAG}_d$D.json 2> $R/gpurun_out/prof_${TAG}_d$D.err
   find $R/gpurun_out/prof_${TAG}_d$D -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_kernel_stats_2048_bench_depth$D.csv \;
 done
 for CFG in "512 3000 1" "4096 400 1" "1024 600 8"; do

@@ -1221,6 +1221,15 @@ struct XbTrace {
     __device__ ~XbTrace() { if (p) p[1] = wall_clock64(); }       // thread 0 leaves the kernel: its last store has been issued (not drained)
 };
 #endif
+// Row groups of the x passes: NB - 1 groups of C map rows and the group of row N/2, which with C - 1 padding rows would run C transforms
+// for one useful row and -- as the (NB)th workgroup on 256 CUs -- close the launch (per-workgroup trace, profiles/r03_xpass_trace.txt:
+// the 257th workgroup of the displacement pass is the only one that shares a CU).  From 1024 up that group runs ONE transform per
+// role (the same engine with a single interleaved column: a quarter of the loads, butterflies and stores), in all three roles.
+template <int N, int C> constexpr bool xpass_single_row_group() { return C > 1 && N >= 1024 && (N / 2) % (2 * C) == 0; }
+// HEIGHT workgroups (2 C rows each: C transforms of two real rows): the groups that hold a valid row, 0 .. N/2 (round 3 also ran the
+// all-padding group behind them)
+template <int N, int C> constexpr int xpass_height_groups() { return (N / 2 + 1 + 2 * C - 1) / (2 * C); }
+
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 {
@@ -1236,7 +1245,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     TwiddleRegs<N, C, T, P, LM> twr;
     twr.load(a.tw, tid);
     constexpr int NB = (HF::NU + C - 1) / C;              // normal workgroups
-    constexpr int HB = JAC ? NB : HF::NUP / (2 * C);      // height workgroups
+    constexpr int HB = JAC ? NB : xpass_height_groups<N, C>();      // height workgroups
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
 
     if constexpr (JAC) {
@@ -1315,7 +1324,18 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             at32(hraw, hraw_index(N, p, u)) = ha;
             at32(hraw, hraw_index(N, p, u + 1)) = hb;
         };
-        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+        // the group of row N/2 holds one valid row: ONE transform (rows N/2 and N/2 + 1) instead of C
+        if constexpr (xpass_single_row_group<N, C>()) {
+            if (u0 == N / 2) {
+                TwiddleRegs<N, 1, T, P, LM> tw1;
+                tw1.load(a.tw, tid);
+                batch_fft<N, 1, T, P>(fbuf, tw1, tid, in, out);
+            } else {
+                batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+            }
+        } else {
+            batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             vmin = fminf(vmin, __shfl_xor(vmin, o));
@@ -1366,6 +1386,32 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             OCEAN_STORE(nrm, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, -o.y, o.z, o.w));
     };
     const c32 zero = make_float2(0.0f, 0.0f);
+    if constexpr (xpass_single_row_group<N, C>()) {
+        if (u0 == N / 2) {           // the group of row N/2: one useful row, one interleaved column per transform
+            using LS1 = LastStage<N, 1, T, P, LM>;
+            if (a.mode == 2) {
+                for_each_output<LS1, T>(tid, [&](int p, int c, int, int) { emit(p, c, zero, zero); });
+                return;
+            }
+            TwiddleRegs<N, 1, T, P, LM> tw1;
+            tw1.load(a.tw, tid);
+            c32 held1[LS1::IT][LS1::RL];
+            {
+                auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z1, nf, u0 + c, -1.0f, uk); };
+                auto out = [&](int, int, c32 v, int u, int i) { held1[u][i] = v; };
+                batch_fft<N, 1, T, P>(fbuf, tw1, tid, in, out);
+            }
+            if (a.mode == 1) {
+                for_each_output<LS1, T>(tid, [&](int p, int c, int u, int i) { emit(p, c, held1[u][i], zero); });
+                return;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z2, nf, u0 + c, 1.0f, uk); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { emit(p, c, held1[u][i], v); };
+            batch_fft<N, 1, T, P>(fbuf, tw1, tid, in, out);
+            return;
+        }
+    }
     if (a.mode == 2) {               // HEIGHT1: the normal map is all zero
         for_each_output<LS, T>(tid, [&](int p, int c, int, int) { emit(p, c, zero, zero); });
         return;
@@ -1452,13 +1498,13 @@ __device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_fla
         a.done_rec[i] = make_uint4(a.minmax[2 * i + 0], a.minmax[2 * i + 1], a.frame_seq, 0u);     // one 16-byte store
 }
 
+
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
-__global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
+__global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
     constexpr int LM = 1;                                 // as in k_xpass_b
-    using LS = LastStage<N, C, T, P, LM>;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
@@ -1471,52 +1517,63 @@ __global__ void __launch_bounds__(T) k_xpass_disp(const FrameArgs a)
     [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
     float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
-    TwiddleRegs<N, C, T, P, LM> twr;
-    twr.load(a.tw, tid);
-    float hv[LS::IT][LS::RL];
-    [[maybe_unused]] float jv[JAC ? LS::IT : 1][JAC ? LS::RL : 1], j0[JAC ? LS::IT : 1][JAC ? LS::RL : 1];
+    // CC = map rows of this workgroup's group (C, or 1 for the group of row N/2)
+    auto rows = [&](auto cc_tag) {
+        constexpr int CC = decltype(cc_tag)::value;
+        using LS = LastStage<N, CC, T, P, LM>;
+        TwiddleRegs<N, CC, T, P, LM> twr;
+        twr.load(a.tw, tid);
+        float hv[LS::IT][LS::RL];
+        [[maybe_unused]] float jv[JAC ? LS::IT : 1][JAC ? LS::RL : 1], j0[JAC ? LS::IT : 1][JAC ? LS::RL : 1];
 #pragma unroll
-    for (int u = 0; u < LS::IT; ++u) {
-        const int w = tid + u * T;
-        if (!LS::GUARD || w < LS::ITEMS) {
-            int c, j;
-            LS::map(w, c, j);
+        for (int u = 0; u < LS::IT; ++u) {
+            const int w = tid + u * T;
+            if (!LS::GUARD || w < LS::ITEMS) {
+                int c, j;
+                LS::map(w, c, j);
 #pragma unroll
-            for (int i = 0; i < LS::RL; ++i) {
-                hv[u][i] = at32(hraw, hraw_index(N, j + i * LS::STRIDE, u0 + c));
-                if constexpr (JAC) {
-                    jv[u][i] = at32(a.jraw + (size_t)tile * HF::HRAW_TILE, hraw_index(N, j + i * LS::STRIDE, u0 + c));
-                    j0[u][i] = at32(a.jac0 + (size_t)tile * HF::HRAW_TILE, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                for (int i = 0; i < LS::RL; ++i) {
+                    hv[u][i] = at32(hraw, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                    if constexpr (JAC) {
+                        jv[u][i] = at32(a.jraw + (size_t)tile * HF::HRAW_TILE, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                        j0[u][i] = at32(a.jac0 + (size_t)tile * HF::HRAW_TILE, hraw_index(N, j + i * LS::STRIDE, u0 + c));
+                    }
                 }
             }
         }
-    }
-    const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];      // final by now
-    if (!a.done_ctr && blockIdx.x == 0 && tid == 0) a.done_rec[tile] = make_uint4(kmn, kmx, a.frame_seq, 0u);
-    const float mn = key_float(kmn);
-    const float mx = key_float(kmx);
-    const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
-    const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
-    auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z0, nf, u0 + c, -1.0f, uu); };
-    auto out = [&](int p, int c, c32 v, int u, int i) {
+        const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];      // final by now
+        if (!a.done_ctr && blockIdx.x == 0 && tid == 0) a.done_rec[tile] = make_uint4(kmn, kmx, a.frame_seq, 0u);
+        const float mn = key_float(kmn);
+        const float mx = key_float(kmx);
+        const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
+        const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
+        auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z0, nf, u0 + c, -1.0f, uu); };
+        auto out = [&](int p, int c, c32 v, int u, int i) {
 #pragma clang fp contract(off)          // as in k_xpass_b
-        const int q = u0 + c;
-        if (q > N / 2) return;
-        const float s = ((p + q) & 1) ? -1.0f : 1.0f;
-        float w = 1.0f;
-        if constexpr (JAC) {        // (1 + l s dxDx)(1 + l s dzDz) - (l s dxDz)(l s dzDx), .cpp:422-426 (the two cross terms are one field)
-            const float cross = lambda * jv[u][i];
-            w = j0[u][i] - cross * cross;
-        }
-        const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, w);
-        OCEAN_STORE(disp, q * N + p, o);
-        if (q != 0 && q != N / 2)       // mirror: the displacements are odd, height and Jacobian even
-            OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, w));
+            const int q = u0 + c;
+            if (q > N / 2) return;
+            const float s = ((p + q) & 1) ? -1.0f : 1.0f;
+            float w = 1.0f;
+            if constexpr (JAC) {        // (1 + l s dxDx)(1 + l s dzDz) - (l s dxDz)(l s dzDx), .cpp:422-426 (the two cross terms are one field)
+                const float cross = lambda * jv[u][i];
+                w = j0[u][i] - cross * cross;
+            }
+            const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, w);
+            OCEAN_STORE(disp, q * N + p, o);
+            if (q != 0 && q != N / 2)       // mirror: the displacements are odd, height and Jacobian even
+                OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, w));
+        };
+        if (a.mode == 2)                 // HEIGHT1: no horizontal displacement, no transform
+            for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
+        else
+            batch_fft<N, CC, T, P>(fbuf, twr, tid, in, out);
     };
-    if (a.mode == 2)                 // HEIGHT1: no horizontal displacement, no transform
-        for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
-    else
-        batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+    if constexpr (xpass_single_row_group<N, C>()) {
+        if (u0 == N / 2) rows(std::integral_constant<int, 1>{});
+        else rows(std::integral_constant<int, C>{});
+    } else {
+        rows(std::integral_constant<int, C>{});
+    }
     if (a.done_ctr) frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
 }
 

@@ -40,7 +40,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_m = sizeof(c32) * fft_lds_elems<N, C>();
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
-    constexpr unsigned hb_b = HF::NUP / (2 * C), nb = (HF::NU + C - 1) / C;
+    constexpr unsigned hb_b = xpass_height_groups<N, C>(), nb = (HF::NU + C - 1) / C;
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     // Which forms of the z pass a tile size has (ocean_kernels.h).  ZW1: one column, two-transform batches (four-transform batches at 256 /
