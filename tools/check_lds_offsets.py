@@ -24,7 +24,18 @@ def pad(x):
     return x + x // 16
 
 
+def pad_x(nsw):
+    """Layout of the exchange written by a stage with NS = nsw in a SINGLE-COLUMN batch (fft_engine.h: lds_index_x / lds_delta_x)."""
+    if nsw == 8:
+        return lambda x: x + 8 * (x // 64)
+    if nsw >= 64:
+        return lambda x: x
+    return pad
+
+
 def violations(plans):
+    """Accesses whose image index is not base + a compile-time constant, plus (single-column layouts) indices beyond the image's
+    N + N/8 slots: the c-interleaved 1/16 image of several columns and the per-exchange layouts of one column, every plan."""
     bad = 0
     for n, pls in plans.items():
         for plan in pls:
@@ -32,15 +43,22 @@ def violations(plans):
             for r in plan:
                 prod *= r
             assert prod == n, (n, plan)
-            ns = 1
-            for r in plan:
+            ns, ns_prev = 1, 1
+            for st, r in enumerate(plan):
                 s = n // r
+                wx, rx = pad_x(ns), pad_x(ns_prev)
                 for j in range(n // r):
                     k = j % ns
                     j0 = (j - k) * r + k
                     for i in range(r):
                         bad += pad(j0 + i * ns) != pad(j0) + pad(i * ns)
                         bad += pad(j + i * s) != pad(j) + pad(i * s)
+                        if st < len(plan) - 1:          # single column: this stage writes the exchange named by its NS
+                            bad += wx(j0 + i * ns) != wx(j0) + wx(i * ns)
+                            bad += wx(j0 + i * ns) >= n + n // 8
+                        if st > 0:                      # ... and reads the one the stage before wrote
+                            bad += rx(j + i * s) != rx(j) + rx(i * s)
+                ns_prev = ns
                 ns *= r
     return bad
 

@@ -225,7 +225,8 @@ template <> struct Plan<2048> : Radices<16, 16, 8> {};
 template <> struct Plan<4096> : Radices<16, 16, 16> {};
 
 template <int N> constexpr int lds_padded() { return N + N / 16; }
-template <int N, int C> constexpr int fft_lds_elems() { return lds_padded<N>() * C; }
+// (a single-column batch lays one of its exchanges out with 1/8 of padding: lds_index_x)
+template <int N, int C> constexpr int fft_lds_elems() { return C == 1 ? N + N / 8 : lds_padded<N>() * C; }
 
 template <int C>
 __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >> 4)) * C + c; }
@@ -236,6 +237,31 @@ __device__ __forceinline__ int lds_index(int idx, int c) { return (idx + (idx >>
 // j0 = (j - k) * R + k, k = j % NS < NS; in both cases (idx0 mod 16) + (d mod 16) < 16, so the padding term idx / 16 splits into
 // idx0 / 16 + d / 16 (checked exhaustively for every plan of this file: tools/check_lds_offsets.py).
 template <int C> constexpr int lds_delta(int d) { return (d + d / 16) * C; }
+
+// Per-exchange layouts of a SINGLE-COLUMN batch (C = 1: k_zpass_c1, the row-N/2 groups of the x passes).  With one column the lanes of a
+// wave hold consecutive butterflies j, so every stage READS 64 consecutive elements per instruction -- conflict-free exactly when the
+// image has no padding inside aligned runs of 32 -- while the WRITES of the stage before scatter with a stride that depends on that
+// stage's NS.  No single padding serves all of them (bank model of ds_read_b64: 2 x 32 lanes on 64 banks, ds_write_b64: 4 x 16 lanes on
+// 32 banks; PMC of round 4: 33 % of the single-transform z pass's LDS cycles were conflicts with the 1/16 padding everywhere), but the
+// exchanges are independent -- all reads, barrier, all writes -- so each gets its own, named by the NS of the stage that WRITES it:
+//     NSW = 1    idx + idx / 16          first-stage writes (stride R) conflict-free; the reads behind them stay 2-way
+//     NSW = 8    idx + 8 * (idx / 64)    writes of 8 lanes x 8 elements land 16 banks apart: both sides conflict-free
+//     NSW >= 64  idx                     writes are contiguous runs of >= 64 elements already: both sides conflict-free
+// (radix-16 first stages -- NSW = 16 -- keep the 1/16 padding).  Weighted by the instruction costs that is 8.5 instead of 12 cycles per
+// element and transform.  The offsets of a butterfly's accesses stay compile-time constants (tools/check_lds_offsets.py checks every
+// plan, stage, butterfly and leg of these layouts too).  Batches of several columns keep the c-interleaved 1/16 image, and so do
+// transforms below 2048 points: at 1024 (128 threads, two waves per workgroup) the new layouts measured 3 % SLOWER (8 x 1024^2 z pass
+// 33.9-34.2 -> 34.9-35.3 us) against -3.5 % at 2048 and -2 % at 4096 (profiles/r04_zpass_experiments.txt).
+template <int C, int NSW, int N> __device__ __forceinline__ int lds_index_x(int idx, int c)
+{
+    if constexpr (C == 1 && N >= 2048 && NSW == 8) return idx + 8 * (idx >> 6);
+    else if constexpr (C == 1 && N >= 2048 && NSW >= 64) return idx;
+    else return lds_index<C>(idx, c);
+}
+template <int C, int NSW, int N> constexpr int lds_delta_x(int d)
+{
+    return (C == 1 && N >= 2048 && NSW == 8) ? d + 8 * (d / 64) : ((C == 1 && N >= 2048 && NSW >= 64) ? d : lds_delta<C>(d));
+}
 
 // Row-major image of the LAST exchange of an LM = 1 batch (the x passes): element (idx, c) at c * lds_row<N>() + idx.  The last stage of
 // that layout reads 64 consecutive idx of ONE column per wave -- in the c-interleaved image those are 32 bytes apart, eight lanes per bank
@@ -319,9 +345,10 @@ template <int N, int C, int T, class P, int LM = 0> struct TwiddleRegs {
 //          serve values it prefetched into registers);  otherwise from LDS
 //   LAST : outputs to out(idx, c, value, u, i) (u, i are unrolled constants);
 //          otherwise to LDS, in place (reads complete -> barrier -> writes)
-template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, bool WRM, class TW, class In, class Out>
+template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, bool WRM, int NSR, class TW, class In, class Out>
 __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
+    // NSR: the NS of the stage that wrote the image this stage reads (lds_index_x: per-exchange layouts of single-column batches)
     // WRM: this stage's outputs feed the last stage of a batch whose last exchange is row-major (lds_row_major_last)
     constexpr bool RRM = LAST && !FIRST && lds_row_major_last<N, C, LM, R>();      // ... and the last stage reads that image
     [[maybe_unused]] constexpr int STAMP_BASE = STAGE;
@@ -343,12 +370,12 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
                 int c, j;
                 last_stage_map<N, C, R, LM>(w, c, j);
                 v2 x[R];
-                [[maybe_unused]] const int rb = RRM ? lds_index_rm<N, C>(j, c) : lds_index<C>(j, c);
+                [[maybe_unused]] const int rb = RRM ? lds_index_rm<N, C>(j, c) : lds_index_x<C, NSR, N>(j, c);
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     if constexpr (FIRST) x[i] = tov(in(j + i * (N / R), c, u, i));
                     else if constexpr (RRM) x[i] = ldsv[rb + i * (N / R)];
-                    else x[i] = ldsv[rb + lds_delta<C>(i * (N / R))];
+                    else x[i] = ldsv[rb + lds_delta_x<C, NSR, N>(i * (N / R))];
                 }
 #ifndef OCEAN_ABL_NOFFT
                 if constexpr (NS > 1) apply_twiddles<R>(x, tov(twr.w[STAGE][u]));
@@ -370,11 +397,11 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
         const int w = tid + u * T;
         if (!GUARD || w < ITEMS) {
             const int c = w % C, j = w / C;
-            [[maybe_unused]] const int rb = lds_index<C>(j, c);
+            [[maybe_unused]] const int rb = lds_index_x<C, NSR, N>(j, c);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if constexpr (FIRST) x[u][i] = tov(in(j + i * (N / R), c, u, i));
-                else x[u][i] = ldsv[rb + lds_delta<C>(i * (N / R))];
+                else x[u][i] = ldsv[rb + lds_delta_x<C, NSR, N>(i * (N / R))];
             }
 #ifndef OCEAN_ABL_NOFFT
             if constexpr (NS > 1) apply_twiddles<R>(x[u], tov(twr.w[STAGE][u]));
@@ -392,9 +419,9 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
             const int c = w % C, j = w / C;
             const int k = j % NS;
             const int j0 = (j - k) * R + k;
-            const int wb = WRM ? lds_index_rm<N, C>(j0, c) : lds_index<C>(j0, c);
+            const int wb = WRM ? lds_index_rm<N, C>(j0, c) : lds_index_x<C, NS, N>(j0, c);
 #pragma unroll
-            for (int i = 0; i < R; ++i) ldsv[wb + (WRM ? i * NS : lds_delta<C>(i * NS))] = x[u][i];
+            for (int i = 0; i < R; ++i) ldsv[wb + (WRM ? i * NS : lds_delta_x<C, NS, N>(i * NS))] = x[u][i];
         }
     }
 }
@@ -403,9 +430,10 @@ template <int N, int C, int T, class P, int STAGE, int NS, int LM, class TW, cla
 __device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
     constexpr int R = P::r[STAGE];
+    constexpr int NSR = STAGE == 0 ? 1 : NS / P::r[STAGE == 0 ? 0 : STAGE - 1];      // the NS of the stage before this one
     constexpr bool FIRST = STAGE == 0, LAST = STAGE == P::S - 1;
     constexpr bool WRM = STAGE == P::S - 2 && lds_row_major_last<N, C, LM, P::last>();
-    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM, WRM>(lds, twr, tid, in, out);
+    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM, WRM, NSR>(lds, twr, tid, in, out);
     OCEAN_STAMP(10 + 3 * STAGE);
     if constexpr (!LAST) {
         __syncthreads();
