@@ -61,7 +61,7 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (abo
 # Bytes per texel each launch of THIS pipeline has to move: half-size
 # intermediates, 16-bit dispersion.  roofline.achieved / frac use the library's own accounting of the measured context
 # (ocean_algorithmic_bytes_per_launch); these are its values for the fp32 seven-field frame, kept for the CPU-side checks.
-KERNEL_BYTES_ACTUAL = {"k_zpass": 23, "k_xpass_b": 28, "k_xpass_disp": 22}
+KERNEL_BYTES_ACTUAL = {"k_zpass": 23, "k_xpass_b": 28, "k_xpass_disp": 22}      # ("k_zpass" = the frame's first launch, whichever kernel form: k_zpass / k_zpass_c1)
 FRAME_BYTES_ACTUAL = 73.0
 # SURVEY.md 8d's MODEL of a plain two-pass scheme with 3.5 full-size complex intermediates (no point
 # symmetry): 108 B/texel per frame.  Not the traffic of this pipeline; reported as `survey_model_*` only.
@@ -443,6 +443,23 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
             ent["rocprof_launch_us"] = st["avg_us"]
             ent["event_over_rocprof"] = us / st["avg_us"]
         kernels[k] = ent
+    # the timed (pipelined) regime's own counter passes: same counters, frames at the bench's pipeline depth (tools/pmc_depth.sh)
+    pipelined_traffic = None
+    if depth > 1:
+        per = {k: traffic.get(key(k) + f":depth{depth}") for k in names}
+        if all(per.values()):
+            total = sum(v["hbm_bytes_per_launch"] for v in per.values())
+            own_frame = own_bytes_per_texel * texels
+            pipelined_traffic = {
+                "bytes_per_launch": {k: v["hbm_bytes_per_launch"] for k, v in per.items()},
+                "bytes_per_frame": total, "algorithmic_bytes_per_frame": own_frame, "over_algorithmic": total / own_frame,
+                "counter_GBps": total / (ms_per_step * 1e-3) * 1e-9, "algorithmic_GBps": own_frame / (ms_per_step * 1e-3) * 1e-9,
+                "source": per[names[0]]["source"],
+                "what": f"FETCH_SIZE x 2 + WRITE_SIZE per launch with frames at pipeline depth {depth} (the store policies and cache state of the "
+                        "timed region; the counter collection serialises the kernels), over this run's ms_per_step.  These counters sit at the "
+                        "L2's memory-side port and count Infinity-Cache hits too (MI355X_MICROARCH.md, HBM section): they show that the "
+                        "pipelined frame moves its algorithmic bytes and no more across that port -- how many of them the 256 MiB cache "
+                        "serves is not observable with them"}
     dom = max(names, key=lambda k: kernels[k]["launch_us"])
     d = kernels[dom]
     tr = traffic.get(key(dom))
@@ -473,6 +490,7 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
         "serial_frame_GBps": frame_own / (serial_us_per_step * 1e-6) * 1e-9,
         "serial_frame_frac": frame_own / (serial_us_per_step * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
         "pipelined_kernel_us": ({k: v * 1e3 for k, v in zip(names, kern_ms_pipe)} if kern_ms_pipe else None),
+        "pipelined_traffic": pipelined_traffic,
         "pipelined_depth": depth,
         "frame_bytes_per_texel": own_bytes_per_texel,
         "frame_GBps": frame_own / (ms_per_step * 1e-3) * 1e-9,

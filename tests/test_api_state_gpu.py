@@ -13,6 +13,8 @@ import threading
 import numpy as np
 import pytest
 
+from conftest import isolated      # tests that share memory across processes or exhaust it run in a pytest process of their own
+
 pytestmark = pytest.mark.gpu
 
 SEED = 0x5EED0000
@@ -197,6 +199,7 @@ def test_two_contexts_from_two_host_threads_match_serial_use():
         assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2]) and want[3] == got[3]
 
 
+@isolated
 def test_exported_maps_are_read_by_another_process_through_the_dmabuf(tmp_path):
     """ocean_export_maps (the remainder): the map set as ONE dma-buf a renderer imports instead of the reference's
     staging-buffer round trip (WaterSurfaceMesh.cpp:642-755).  Without Vulkan on the image, the importer is a second process that maps the
@@ -241,6 +244,7 @@ def test_exported_maps_are_read_by_another_process_through_the_dmabuf(tmp_path):
     b.close()
 
 
+@isolated
 def test_importer_sees_every_frame_right_after_the_synchronous_call(tmp_path):
     """The ordering contract of include/ocean.h for readers OUTSIDE the context's streams: a completion record
     is not a memory fence, so once a map set has been exported ocean_compute_waves / ocean_wait_frame synchronise the frame's stream instead
@@ -315,6 +319,7 @@ def test_python_mirror_async_pair_matches_the_blocking_call():
     assert ws.ComputeWaves(6.0) == pytest.approx(ws.ComputeWaves(6.0))
 
 
+@isolated
 def test_maps_written_into_memory_another_process_owns(tmp_path):
     """ocean_bind_output_dmabuf, the other direction of the interop: the renderer owns the memory and hands a dma-buf in.  Here this process
     owns it (a context's exported map set stands in for a VkDeviceMemory), a CHILD process imports the descriptor, binds it as its output and
@@ -352,6 +357,7 @@ def test_maps_written_into_memory_another_process_owns(tmp_path):
     owner.close()
 
 
+@isolated
 def test_dmabuf_binding_leaves_the_descriptor_with_the_caller():
     """ocean_bind_output_dmabuf inside ONE process (an allocation of another context stands in for the renderer's), twice with the same
     descriptor: the import holds its own reference, the caller's descriptor stays open and usable through import, re-binding, un-binding and
@@ -391,6 +397,7 @@ def test_dmabuf_binding_leaves_the_descriptor_with_the_caller():
     owner.close(); ref.close()
 
 
+@isolated
 def test_out_of_memory_is_reported_as_such_and_leaves_the_device_usable():
     """A context that cannot fit (60 000 tiles of 4096^2: 8 TB of spectrum alone) is refused with OCEAN_E_NOMEM -- not a generic HIP error, no
     handle, nothing left allocated -- and the next context works and delivers the usual frame (the failed allocation's sticky HIP error is cleared)."""

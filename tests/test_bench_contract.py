@@ -185,11 +185,13 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The roofline fractions of the committed default bench line (profiles/r03z_bench_default.json) can be recomputed from
-    the committed rocprofv3 summary (profiles/kernel_stats.json <- r03z_kernel_stats_2048_bench_depth1.csv) and the byte
-    accounting of this file: every kernel within 6 %, nothing above 1, and the summaries regenerate from the CSV."""
+    """The roofline fractions of the committed default bench line (profiles/r04d_bench_default.json) can be recomputed from
+    the committed rocprofv3 summary (profiles/kernel_stats.json <- r04d_kernel_stats_2048_bench_depth1.csv) and the byte
+    accounting of this file: every kernel within 8 % (two processes: the hardware queue a context's stream lands on moves a kernel by up
+    to +-1 us, profiles/r03_bimodal_probe.txt section 4a -- 6 % of the 17 us displacement pass), nothing above 1, and the summaries
+    regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    line = [l for l in open(os.path.join(prof, "r03z_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(prof, "r04d_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
@@ -197,17 +199,25 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     assert d["config"]["tile_size"] == 2048 and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
     for k, b in bench.KERNEL_BYTES_ACTUAL.items():
         frac_from_rocprof = b * n2 / (st[k + "@2048"]["avg_us"] * 1e-6) * 1e-9 / bench.HBM_PEAK_GBPS
-        assert abs(r["kernels"][k]["frac"] - frac_from_rocprof) <= 0.06 * frac_from_rocprof, (k, r["kernels"][k]["frac"], frac_from_rocprof)
+        assert abs(r["kernels"][k]["frac"] - frac_from_rocprof) <= 0.08 * frac_from_rocprof, (k, r["kernels"][k]["frac"], frac_from_rocprof)
         assert r["kernels"][k]["frac"] < 1.0
     assert r["frac"] == r["kernels"][r["kernel"]]["frac"] and r["frame_frac"] < 1.0 and r["serial_frame_frac"] < 1.0
     assert abs(r["frame_frac"] - bench.FRAME_BYTES_ACTUAL * n2 / (d["ms_per_step"] * 1e-3) * 1e-9 / bench.HBM_PEAK_GBPS) < 1e-9
+    # round 4: the timed region is repeated and reported as median with spread; the CPU baseline names the usable cores
+    assert d["timing"]["regions"] >= 7 and d["timing"]["ms_per_step_p10"] <= d["ms_per_step"] <= d["timing"]["ms_per_step_p90"]
+    assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["nproc"] and d["cpu_baseline"]["cores"] == d["cpu_baseline"]["host"]["usable_cpus"]
+    assert {"4096x4096_fp32_depth3", "4096x4096_fp16_spectrum_depth3", "4096x4096_fp16_intermediates_depth3"} <= set(d["extra"])
+    assert d["extra"]["4096x4096_fp32_depth3"]["error_vs_float64_oracle"] <= 1e-5 < d["extra"]["4096x4096_fp16_spectrum_depth3"]["error_vs_float64_oracle"] <= 1e-3
     # the summary itself regenerates from the committed CSV
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r03z_kernel_stats_2048_bench_depth1.csv"))):
-        m = re.search(r"(k_[a-z_]+)<2048", row["Name"])
-        if m and m.group(1) in bench.KERNEL_BYTES_ACTUAL:
-            a = acc.setdefault(m.group(1), [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
+    for row in csv.DictReader(open(os.path.join(prof, "r04d_kernel_stats_2048_bench_depth1.csv"))):
+        m = re.search(r"(k_[a-z_0-9]+)<2048", row["Name"])
+        name = m.group(1) if m else None
+        if name and name.startswith("k_zpass"):          # the z pass's kernel forms (k_zpass, k_zpass_c1) are all the frame's first launch
+            name = "k_zpass"
+        if name in bench.KERNEL_BYTES_ACTUAL:
+            a = acc.setdefault(name, [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
     for k, (calls, total) in acc.items():
         assert abs(total / calls * 1e-3 - st[k + "@2048"]["avg_us"]) < 1e-6

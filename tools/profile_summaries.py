@@ -4,7 +4,8 @@
   profiles/traffic.json        HBM bytes per launch from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
 
 usage: profile_summaries.py stats <kernel_stats.csv> [tiles] ...   (kernels keyed name@N, or name@NxT for T tiles)
-       profile_summaries.py traffic <pmc_summary.txt> <N> [tiles] [fetch_factor]
+       profile_summaries.py traffic <pmc_summary.txt> <N> [tiles] [fetch_factor] [depth]
+       (depth > 1: counter passes of PIPELINED frames, tools/pmc_depth.sh -- keyed name@N:depthD, what bench.py's roofline.pipelined_traffic quotes)
 Entries are merged into the existing JSON files.  FETCH_SIZE is multiplied by `fetch_factor` (default 2.0: gfx950
 tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md HBM section; tools/ubench/fetchcal.hip calibrates the
 factor for the access widths of these kernels, see profiles/README.md); WRITE_SIZE is taken as read.
@@ -73,7 +74,7 @@ def stats(path, tiles=1):
     save("kernel_stats.json", out)
 
 
-def traffic(path, n, tiles=1, fetch_factor=2.0):
+def traffic(path, n, tiles=1, fetch_factor=2.0, depth=1):
     out = load("traffic.json")
     cur = None
     vals = {}
@@ -87,10 +88,12 @@ def traffic(path, n, tiles=1, fetch_factor=2.0):
     for k, v in vals.items():
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
-        key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "")
+        key = f"{k}@{n}" + (f"x{tiles}" if tiles > 1 else "") + (f":depth{depth}" if depth > 1 else "")
         ent = {"hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * fetch_factor + v["WRITE_SIZE"] * 1024),
                "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"], "fetch_factor": fetch_factor,
-               "source": rel(path) + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)",
+               "source": rel(path) + (" (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc3.sh)" if depth == 1 else
+                                      f" (the same counters over frames at pipeline depth {depth}: non-temporal map stores, {depth} chains rotating "
+                                      "through the memory-side cache; tools/pmc_depth.sh)"),
                "kernel_source_sha16": _sha()}
         if k == "k_zpass":
             ent["correction"] = (f"FETCH_SIZE x {fetch_factor}: its loads are coalesced (16 / 4 bytes per lane), for which "
@@ -112,6 +115,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     elif sys.argv[1] == "traffic":
-        traffic(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1, float(sys.argv[5]) if len(sys.argv) > 5 else 2.0)
+        traffic(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1, float(sys.argv[5]) if len(sys.argv) > 5 else 2.0,
+                int(sys.argv[6]) if len(sys.argv) > 6 else 1)
     else:
         raise SystemExit(__doc__)
