@@ -354,6 +354,9 @@ def test_maps_written_into_memory_another_process_owns(tmp_path):
     assert L.ocean_bind_output_dmabuf(owner._h, -1, 1 << 20, 0, 0) == _abi.OCEAN_E_INVALID
     assert L.ocean_bind_output_dmabuf(owner._h, 0, 16, 0, 0) == _abi.OCEAN_E_INVALID              # too small for the maps
     assert L.ocean_bind_output_dmabuf(owner._h, 0, nbytes, 0, 64) == _abi.OCEAN_E_INVALID         # overlapping maps
+    # offsets so large that offset + map size wraps around must not pass the bounds check
+    assert L.ocean_bind_output_dmabuf(owner._h, 0, nbytes, (1 << 64) - 16, 0) == _abi.OCEAN_E_INVALID
+    assert L.ocean_bind_output_dmabuf(owner._h, 0, nbytes, 0, (1 << 64) - 32) == _abi.OCEAN_E_INVALID
     owner.close()
 
 
@@ -438,6 +441,14 @@ def test_stream_selection_orders_the_queues_and_changes_no_bit():
     b = W.OceanBatch(n, 1, 0)
     assert _abi.lib().ocean_select_streams(b._h, 10, None) == _abi.OCEAN_E_NOT_READY        # before ocean_prepare
     b.prepare(SEED + 3)
+    # with caller-bound output the calibration frames would land in the caller's memory: refused, and the memory stays untouched
+    import torch
+    mine = torch.full((2, n, n, 4), -7.0, dtype=torch.float32, device="cuda:0")
+    b.bind_output(mine[0].data_ptr(), mine[1].data_ptr())
+    assert _abi.lib().ocean_select_streams(b._h, 10, None) == _abi.OCEAN_E_UNSUPPORTED
+    b.synchronize()
+    assert bool((mine == -7.0).all())
+    b.bind_output(None, None)
     a0 = b.compute_waves(0.5)
     us = b.select_streams(30)
     assert len(us) == 4 and all(u > 0 for u in us) and us == sorted(us)
