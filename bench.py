@@ -77,7 +77,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--regions", type=int, default=9, help="timed regions of --steps frames each (>= 7): ms_per_step is their median, p10 / p90 beside it")
-    ap.add_argument("--prewarm", type=int, default=500, help="untimed frames before the W warm-up steps (brings the device to its steady state even when W is small)")
+    ap.add_argument("--prewarm", type=int, default=2000, help="untimed frames before the W warm-up steps (brings the device to its steady state even when W is small: 0.1 s)")
     ap.add_argument("--size", type=int, default=2048, help="tile size N (default: the roofline config, 2048)")
     ap.add_argument("--tiles", type=int, default=1, help="independent tiles per rank per step")
     ap.add_argument("--depth", type=int, default=3, help="frame pipeline depth of the asynchronous API (1 = strictly serial frames)")

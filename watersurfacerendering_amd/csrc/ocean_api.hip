@@ -159,6 +159,7 @@ static int sync_all(ocean_ctx* c)
     if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
     for (bool& p : c->gather_pending) p = false;
     c->consumer_pending = false;
+    c->burst_pos = 0; c->z_last_set = -1;          // the pipeline is empty: the next pipelined frames start staggered (enqueue_frame)
     return OCEAN_OK;
 }
 #define SYNC_ALL(c) do { int rc_ = sync_all(c); if (rc_) return rc_; } while (0)
@@ -248,6 +249,7 @@ void ocean_destroy(ocean_t* c)
     if (c->consumer_ev) (void)hipEventDestroy(c->consumer_ev);
     if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->z_done) if (e) (void)hipEventDestroy(e);
     for (auto& row : c->mark_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) (void)hipStreamDestroy(c->own[i]);
@@ -531,6 +533,21 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // bit mask of the store policies
     if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 24);
 #endif
+    // The first frames after a drain start STAGGERED: chains that begin together run the same kind of kernel side by side -- three z passes,
+    // then three normal-map passes ... -- and stay in that lockstep for dozens of frames (the steady state has a z pass beside the other
+    // chains' map passes); so frame k = 1 .. depth-1 of a fresh burst starts its z pass behind the z pass of frame k-1 (one event each).
+    // Bursts of 20 / 100 / 1000 frames at 2048^2, depth 3: 52.6 / 49.6 / 47.9 -> 51.6 / 48.0 / 47.3 us per frame (tools/burst_probe.py;
+    // chaining EVERY frame's z pass instead costs 8 us per frame: profiles/r04_zpass_experiments.txt item 5).
+    c->after_z = nullptr;
+    if (pipe) {
+        if (c->burst_pos < c->depth) {
+            if (!c->z_done[set]) HIP_TRY(hipEventCreateWithFlags(&c->z_done[set], hipEventDisableTiming));
+            if (c->z_last_set >= 0 && c->z_last_set != set && c->z_done[c->z_last_set]) HIP_TRY(hipStreamWaitEvent(st, c->z_done[c->z_last_set], 0));
+            c->after_z = c->z_done[set];
+            c->z_last_set = set;
+        }
+        if (c->burst_pos < MAXD + 1) c->burst_pos++;
+    }
     hipError_t e = hipErrorInvalidValue;
     if (c->n <= 256) e = ocean_launch_frame_small(c, a, stream_maps, st, marks);
     else if (c->n <= 1024) e = ocean_launch_frame_mid(c, a, stream_maps, st, marks);

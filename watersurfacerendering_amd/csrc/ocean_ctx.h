@@ -96,6 +96,10 @@ struct ocean_ctx {
     hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
     hipEvent_t mark_ev[MAXD][6] = {};   // per-launch timing: (start, stop) of each of the three kernels of a frame
     ocean_launch_info last_launch[3] = {};  // what the most recent frame launched (ocean_last_launch)
+    hipEvent_t z_done[MAXD] = {};       // pipelined frames right after a drain: recorded behind a chain's z pass (see enqueue_frame)
+    hipEvent_t after_z = nullptr;       // what launch_frame records behind the z pass of the frame being enqueued (null: nothing)
+    int burst_pos = 0;                  // pipelined frames enqueued since the context's streams were last drained
+    int z_last_set = -1;
     hipEvent_t consumer_ev = nullptr;   // behind the most recent consumer launch (mips, grid): the context-wide output buffers of
     hipStream_t consumer_stream = nullptr;  // those are re-used, so a consumer launch on ANOTHER chain's stream first waits for it
     bool consumer_pending = false;

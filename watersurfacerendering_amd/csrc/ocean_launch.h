@@ -133,6 +133,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #undef OCEAN_ZPASS2
 #undef OCEAN_ZPASS3
         if (!launched) return hipErrorInvalidConfiguration;     // (a form this build does not carry: the rules above never ask for one)
+        if (c->after_z) (void)hipEventRecord(c->after_z, st);   // the first frames after a drain: the next chain's z pass starts behind this one (ocean_api.hip)
     }
 #ifdef OCEAN_STAMPS
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
