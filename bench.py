@@ -694,8 +694,10 @@ def main():
         t0 = time.perf_counter()
         for j in range(args.steps):
             b.compute_waves_async(DT * (args.warmup + r * args.steps + j))
-        sync(); barrier(); sync()
-        region_s.append(wdist.max_over_ranks(time.perf_counter() - t0, device=red_dev))
+        sync()
+        t1 = time.perf_counter()         # this rank's K steps are done; the closing barrier + synchronise follow, and the region's time is
+        barrier(); sync()                # the MAX over ranks of (t1 - t0): all ranks left the opening barrier together, so that is the time
+        region_s.append(wdist.max_over_ranks(t1 - t0, device=red_dev))     # until the slowest one finished -- without the barrier's own latency
     import numpy as _np
     reg = _np.sort(_np.asarray(region_s, dtype=_np.float64))
     elapsed = float(_np.median(reg))
