@@ -4,7 +4,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B only)
 import watersurfacerendering_amd as W
-b = W.OceanBatch(2048, 1, 0); b.set_pipeline_depth(3); b.prepare(1)
+DEPTH = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+b = W.OceanBatch(2048, 1, 0); b.set_pipeline_depth(DEPTH); b.prepare(1)
+print("depth", DEPTH)
 DT=0.016
 for j in range(500): b.compute_waves_async(DT*j)
 b.synchronize(); torch.cuda.synchronize()
@@ -15,7 +17,7 @@ def T(f, n=50):
     xs.sort(); return xs[len(xs)//2]
 print("idle b.synchronize us", T(b.synchronize))
 print("idle torch.cuda.synchronize us", T(torch.cuda.synchronize))
-for K in (20, 100, 1000):
+for K in (20, 21, 24, 100, 1000):
     rows=[]
     for rep in range(15):
         b.synchronize(); torch.cuda.synchronize()
