@@ -1,6 +1,6 @@
 """Timeline of a burst of K pipelined frames between two drains (developer tool; what bench.py --steps 20 times per region).
   run:      rocprofv3 --kernel-trace --output-format csv -d gpurun_out/bt -- python3 tools/burst_trace.py run [K] [depth]
-  analyse:  python3 tools/burst_trace.py show <kernel_trace.csv> [K]
+  analyse:  python3 tools/burst_trace.py show <kernel_trace.csv> [K] [first frame] [frames]
 Prints, for the median burst: first start -> last end, and per frame the start offset and duration of its three kernels."""
 import csv, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ def run(K, depth):
         b.synchronize(); torch.cuda.synchronize()
     b.close()
 
-def show(path, K):
+def show(path, K, first=0, count=None):
     rows = []
     for r in csv.DictReader(open(path)):
         m = re.search(r"(k_[a-z_0-9]+)<", r["Kernel_Name"])
@@ -34,7 +34,7 @@ def show(path, K):
     seq = {"z": [], "b": [], "d": []}
     for s, e, k in bu: seq[k].append(((s - t0) * 1e-3, (e - s) * 1e-3))
     prev_end = 0.0
-    for f in range(K):
+    for f in range(first, K if count is None else min(K, first + count)):
         z, x, d = seq["z"][f], seq["b"][f], seq["d"][f]
         end = d[0] + d[1]
         print(f"frame {f:2d}: z @{z[0]:7.1f} {z[1]:5.1f} | b @{x[0]:7.1f} {x[1]:5.1f} | d @{d[0]:7.1f} {d[1]:5.1f} -> end {end:7.1f} (+{end - prev_end:5.1f})")
@@ -44,4 +44,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 20, int(sys.argv[3]) if len(sys.argv) > 3 else 3)
     else:
-        show(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+        show(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 20, int(sys.argv[4]) if len(sys.argv) > 4 else 0, int(sys.argv[5]) if len(sys.argv) > 5 else None)
