@@ -534,8 +534,9 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 24);
 #endif
     // The first frames after a drain start STAGGERED: chains that begin together run the same kind of kernel side by side -- three z passes,
-    // then three normal-map passes ... -- and stay in that lockstep for dozens of frames (the steady state has a z pass beside the other
-    // chains' map passes); so frame k = 1 .. depth-1 of a fresh burst starts its z pass behind the z pass of frame k-1 (one event each).
+    // then three normal-map passes ... -- and stay in that lockstep for dozens of frames (in the steady state one chain runs half a period
+    // away from the other two: profiles/r04_zpass_experiments.txt item 9); so frame k = 1 .. depth-1 of a fresh burst starts its z pass
+    // behind the z pass of frame k-1 (one event each).
     // Bursts of 20 / 100 / 1000 frames at 2048^2, depth 3: 52.6 / 49.6 / 47.9 -> 51.6 / 48.0 / 47.3 us per frame (tools/burst_probe.py;
     // chaining EVERY frame's z pass instead costs 8 us per frame: profiles/r04_zpass_experiments.txt item 5).
     c->after_z = nullptr;
