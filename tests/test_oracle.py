@@ -138,6 +138,39 @@ def test_lambda_takes_effect_without_prepare():
     assert np.array_equal(d1[..., 1], d2[..., 1])
 
 
+def test_animation_loops_with_the_period_and_fields_are_linear_in_xi():
+    """Two properties of the reference's algorithm that hold at every size (the GPU tests repeat them at 2048^2):
+    (a) the dispersion is quantised to multiples of the base frequency 2 pi / T (QDispersion, .h:284-287) so that the animation LOOPS: the frame at
+        t + T is the frame at t, up to the rounding of the single fp32 product omega * t (.h:267): |omega T - 2 pi q| <= ulp(omega T) / 2, i.e. a
+        phase error of at most 2^-24 * omega * T ~ 4e-5 rad at the largest omega of these tiles -> 1e-4 of a channel's maximum;
+    (b) h0 = ((1/sqrt 2) xi) sqrt P (.h:237-243) is linear in xi and everything after it is linear in h0: doubling xi doubles every raw field and A,
+        exactly (a power of two commutes with every fp32 rounding above the subnormal range), and leaves the normalised height as it was."""
+    n = 64
+    rng = np.random.default_rng(7)
+    xi = rng.standard_normal((n, n, 2)).astype(np.float32)
+    o = O.Oracle(n); o.prepare(xi=xi)
+    period = 200.0
+    for t in (0.0, 3.25):
+        a0, d0, q0 = o.compute_waves(t, fft=O.FFT_F64)
+        a1, d1, q1 = o.compute_waves(t + period, fft=O.FFT_F64)
+        assert abs(a1 - a0) <= 1e-4 * a0
+        for c in range(4):
+            assert np.abs(d1[..., c] - d0[..., c]).max() <= 1e-4 * max(np.abs(d0[..., c]).max(), 1e-30)
+            assert np.abs(q1[..., c] - q0[..., c]).max() <= 1e-4 * np.abs(q0[..., c]).max()
+    # half a period later the frame is a different one (the property above is not vacuous)
+    _, dh, _ = o.compute_waves(0.5 * period, fft=O.FFT_F64)
+    _, d0, _ = o.compute_waves(0.0, fft=O.FFT_F64)
+    assert np.abs(dh[..., 0] - d0[..., 0]).max() > 0.1 * np.abs(d0[..., 0]).max()
+    o2 = O.Oracle(n); o2.prepare(xi=2.0 * xi)
+    a, d, q = o.compute_waves(1.5, fft=O.FFT_F32)
+    a2, d2, q2 = o2.compute_waves(1.5, fft=O.FFT_F32)
+    tiny = 1e-30            # (values that left the normal range on the way are not exact multiples)
+    assert abs(a2 - 2.0 * a) <= 1e-6 * a2
+    assert np.abs(q2 - 2.0 * q).max() <= 1e-6 * np.abs(q2).max() + tiny
+    assert np.abs(d2[..., [0, 2]] - 2.0 * d[..., [0, 2]]).max() <= 1e-6 * np.abs(d2[..., [0, 2]]).max() + tiny
+    assert np.abs(d2[..., 1] - d[..., 1]).max() <= 1e-6
+
+
 def test_reference_output_point_symmetry():
     """h~(k) is real for every k (.cpp:131-135, .h:265-275) => every output field is even or odd
     under (p,q) -> (-p,-q) mod N: height and dD/dx even, displacements and slopes odd.

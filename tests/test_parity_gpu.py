@@ -241,6 +241,39 @@ def test_full_size_against_oracle_and_properties(n):
     b.close()
 
 
+def test_full_size_animation_loop_and_linearity_in_xi():
+    """Size-independent properties at BASELINE's headline size (tests/test_oracle.py states and derives them for the oracle):
+    the animation loops with the period T -- frame(t + T) = frame(t) to 1e-4 of a channel's maximum, the rounding of the single fp32
+    product omega * t (.h:267) -- and every raw field is linear in xi: doubling xi doubles displacements, normals and A (1e-6: a power of two
+    commutes with fp32 rounding) and leaves the normalised height unchanged."""
+    n = 2048
+    period = 200.0
+    b = make_gpu(n, None, seed=0x5EED0000)
+    xi = b.read_xi(0)
+    frames = {}
+    for t in (0.0, 3.25, 3.25 + period, period, 0.5 * period):
+        a = float(b.compute_waves(t)[0])
+        d, q = b.read_maps()
+        frames[t] = (a, d[0].copy(), q[0].copy())
+    for t in (0.0, 3.25):
+        (a0, d0, q0), (a1, d1, q1) = frames[t], frames[t + period]
+        assert abs(a1 - a0) <= 1e-4 * a0
+        for c in (0, 1, 2):
+            assert np.abs(d1[..., c] - d0[..., c]).max() <= 1e-4 * np.abs(d0[..., c]).max(), ("displacement", c)
+        for c in range(4):
+            assert np.abs(q1[..., c] - q0[..., c]).max() <= 1e-4 * np.abs(q0[..., c]).max(), ("normal", c)
+    assert np.abs(frames[0.5 * period][1][..., 0] - frames[0.0][1][..., 0]).max() > 0.1 * np.abs(frames[0.0][1][..., 0]).max()
+    b2 = make_gpu(n, (2.0 * xi)[None])
+    a2 = float(b2.compute_waves(3.25)[0])
+    d2, q2 = b2.read_maps()
+    a, d, q = frames[3.25]
+    assert abs(a2 - 2.0 * a) <= 1e-6 * a2
+    assert np.abs(q2[0] - 2.0 * q).max() <= 1e-6 * np.abs(q2[0]).max()
+    assert np.abs(d2[0][..., [0, 2]] - 2.0 * d[..., [0, 2]]).max() <= 1e-6 * np.abs(d2[0][..., [0, 2]]).max()
+    assert np.abs(d2[0][..., 1] - d[..., 1]).max() <= 1e-6
+    b.close(); b2.close()
+
+
 def test_lambda_scales_displacement_only():
     n = 256
     b = make_gpu(n, None, seed=5)
