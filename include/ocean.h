@@ -402,8 +402,12 @@ enum {
     OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64,  /* (rounds 2-3: the columns of a partially filled last round of z-pass workgroups split
                                             over two workgroups each; never set since round 4 -- the single-transform form
                                             replaced it -- the value stays reserved)                                    */
-    OCEAN_LAUNCH_SINGLE_TRANSFORM = 128  /* z pass: one transform per batch, half the threads (k_zpass_c1): two independent
+    OCEAN_LAUNCH_SINGLE_TRANSFORM = 128, /* z pass: one transform per batch, half the threads (k_zpass_c1): two independent
                                             workgroups per CU where the two-transform forms fit only one (4096^2)       */
+    OCEAN_LAUNCH_STAGGERED_START = 256   /* not a variant (same instantiation, same bits): the launch's workgroups, all resident
+                                            at once, start spread over a few microseconds so that the early ones store while
+                                            the late ones still load -- the z pass and the displacement pass of a serial frame
+                                            of one 2048^2 tile (seven fields, fp32), nowhere else                       */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

@@ -44,6 +44,7 @@ SYMBOLS = [
 
 OCEAN_LAUNCH_NT_MAPS, OCEAN_LAUNCH_NT_INTER, OCEAN_LAUNCH_HALF_INTER, OCEAN_LAUNCH_JACOBIAN = 1, 2, 4, 8
 OCEAN_LAUNCH_FP16_SPECTRUM, OCEAN_LAUNCH_FP32_DISPERSION, OCEAN_LAUNCH_SPLIT_LAST_ROUND, OCEAN_LAUNCH_SINGLE_TRANSFORM = 16, 32, 64, 128
+OCEAN_LAUNCH_STAGGERED_START = 256
 
 
 class OceanError(RuntimeError):

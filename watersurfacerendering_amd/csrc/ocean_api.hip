@@ -504,6 +504,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     }
     a.t = t;
     a.mode = c->mode;
+    a.start_ramp = 0;       // (set per launch by the launcher where a staggered start pays: ocean_launch.h)
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
     const double texels = (double)c->tiles * (double)c->n * (double)c->n;
     // several frames in flight, or maps that would push everything else out of the 256 MiB memory-side cache anyway
@@ -526,10 +527,10 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         const double resident = texels * (10.0 + inter * c->depth);
         if (resident > 300.0e6) stream_maps |= 4;
     }
-    if (!pipe) stream_maps |= 16;                                               // this frame has the device to itself
+    if (!pipe) stream_maps |= 16;                                               // this frame has the device to itself (staggered start: ocean_launch.h)
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
-    static const char* const split_env = getenv("OCEAN_ZSPLIT");                // 0 = never split the last round
-    if (split_env && atoi(split_env) == 0) stream_maps &= ~16;
+    static const char* const ramp_env = getenv("OCEAN_START_RAMP");             // 0 = never stagger the start of a serial frame's workgroups
+    if (ramp_env && atoi(ramp_env) == 0) stream_maps &= ~16;
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // bit mask of the store policies
     if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 24);
 #endif

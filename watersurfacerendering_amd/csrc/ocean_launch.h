@@ -41,6 +41,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb_b = xpass_height_groups<N, C>(), nb = (HF::NU + C - 1) / C;
+    // Staggered start (ocean_kernels.h: start_ramp_wait) for the one frame it was measured to pay for: a frame that has the device to itself
+    // (bit 4 of stream_maps: a serial frame), one 2048^2 tile, all seven fields, fp32 intermediates -- every launch one resident round.
+    const bool fast = !a.h0h && a.omega_q;       // the usual form of the spectrum: fp32 h0, 16-bit dispersion
+    const bool ramp = N == 2048 && tiles == 1 && (stream_maps & 16) && a.mode == 0 && !(stream_maps & 8) && fast;
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     // Which forms of the z pass a tile size has (ocean_kernels.h).  ZW1: one column, two-transform batches (four-transform batches at 256 /
@@ -91,7 +95,6 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     {
         // the form of the z pass (see above); the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the
         // other forms' code (FAST)
-        const bool fast = !a.h0h && a.omega_q;
         bool c1 = HASC1 && zpass_c1_pays<N>(stream_maps, tiles);
         bool zw2 = HAS2 && !c1 && (stream_maps & 4);
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
@@ -103,7 +106,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
         unsigned gx = zw2 ? N / 4 + 1 : N / 2 + 1;
         FrameArgs za = a;
-        za.zfull = (int)gx;
+        // a serial frame of one 2048^2 tile: the single-transform form's 1025 workgroups are one resident round -- staggered start (start_ramp_wait)
+        za.start_ramp = (c1 && ramp) ? 500 : 0;
 #if defined(OCEAN_STAMPS) || defined(OCEAN_DEVELOPER)
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
 #endif
@@ -117,7 +121,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.lds_bytes = (uint32_t)lds;
             li.flags = ((stream_maps & 4) ? OCEAN_LAUNCH_NT_INTER : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
                        (a.mode == 3 ? OCEAN_LAUNCH_JACOBIAN : 0u) | (a.h0h ? OCEAN_LAUNCH_FP16_SPECTRUM : 0u) |
-                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (c1 ? OCEAN_LAUNCH_SINGLE_TRANSFORM : 0u);
+                       (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (c1 ? OCEAN_LAUNCH_SINGLE_TRANSFORM : 0u) |
+                       (za.start_ramp ? OCEAN_LAUNCH_STAGGERED_START : 0u);
         }
         bool launched = false;
 #define OCEAN_ZPASS3(znt, z16, fast) \
@@ -154,27 +159,29 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.per_workgroup = C;
             li.lds_bytes = (uint32_t)(k == 1 ? lds_b : lds_m);
             li.flags = ((stream_maps & (k == 1 ? 1 : 2)) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
-                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u);
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | ((k == 2 && ramp) ? OCEAN_LAUNCH_STAGGERED_START : 0u);
         }
-#define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16)                                                                \
-        do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, a);          \
-             else launch(kern<N, C, G::T_C, typename G::PC, nts, z16, false>, grid, blk, lds, st, ev, a); } while (0)
-#define OCEAN_XPASS(kern, grid, lds, ev, nts)                                                                       \
-        do { if (stream_maps & 8) OCEAN_XPASS2(kern, grid, lds, ev, nts, true);                                       \
-             else OCEAN_XPASS2(kern, grid, lds, ev, nts, false); } while (0)
+#define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16, args)                                                          \
+        do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, args);       \
+             else launch(kern<N, C, G::T_C, typename G::PC, nts, z16, false>, grid, blk, lds, st, ev, args); } while (0)
+#define OCEAN_XPASS(kern, grid, lds, ev, nts, args)                                                                 \
+        do { if (stream_maps & 8) OCEAN_XPASS2(kern, grid, lds, ev, nts, true, args);                                 \
+             else OCEAN_XPASS2(kern, grid, lds, ev, nts, false, args); } while (0)
 #ifdef OCEAN_XB_TRACE
         {   // diagnostic: this translation unit's copy of the trace pointer, set when the context's buffer changes (not per frame)
             static unsigned long long* armed = nullptr;
             if (armed != c->stamps) { armed = c->stamps; (void)hipMemcpyToSymbol(HIP_SYMBOL(ocean::g_xb_trace), &armed, sizeof(armed)); }
         }
 #endif
-        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true);
-        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false);
+        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true, a);
+        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false, a);
 #ifdef OCEAN_STAMPS
         arm(2);
 #endif
-        if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true);
-        else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false);
+        FrameArgs da = a;
+        da.start_ramp = ramp ? 450 : 0;     // its 257 workgroups are one per CU: the same read-then-write burst
+        if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true, da);
+        else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false, da);
 #undef OCEAN_XPASS2
 #undef OCEAN_XPASS
     }
