@@ -159,7 +159,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.per_workgroup = C;
             li.lds_bytes = (uint32_t)(k == 1 ? lds_b : lds_m);
             li.flags = ((stream_maps & (k == 1 ? 1 : 2)) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
-                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | ((k == 2 && ramp) ? OCEAN_LAUNCH_STAGGERED_START : 0u);
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | (ramp ? OCEAN_LAUNCH_STAGGERED_START : 0u);
         }
 #define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16, args)                                                          \
         do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, args);       \
@@ -173,8 +173,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             if (armed != c->stamps) { armed = c->stamps; (void)hipMemcpyToSymbol(HIP_SYMBOL(ocean::g_xb_trace), &armed, sizeof(armed)); }
         }
 #endif
-        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true, a);
-        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false, a);
+        FrameArgs ba = a;
+        ba.start_ramp = ramp ? 450 : 0;     // over its normal-map workgroups (the height workgroups start at once)
+        if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true, ba);
+        else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false, ba);
 #ifdef OCEAN_STAMPS
         arm(2);
 #endif
