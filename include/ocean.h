@@ -406,8 +406,8 @@ enum {
                                             workgroups per CU where the two-transform forms fit only one (4096^2)       */
     OCEAN_LAUNCH_STAGGERED_START = 256   /* not a variant (same instantiation, same bits): the launch's workgroups, all resident
                                             at once, start spread over a few microseconds so that the early ones store while
-                                            the late ones still load -- the three launches of a serial frame of one 2048^2
-                                            tile (seven fields, fp32), nowhere else                                     */
+                                            the late ones still load -- the three launches of a frame of one 2048^2 tile
+                                            (seven fields, fp32; serial and pipelined frames with ramps of their own)     */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

@@ -527,10 +527,8 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         const double resident = texels * (10.0 + inter * c->depth);
         if (resident > 300.0e6) stream_maps |= 4;
     }
-    if (!pipe) stream_maps |= 16;                                               // this frame has the device to itself (staggered start: ocean_launch.h)
+    if (!pipe) stream_maps |= 16;                                               // this frame has the device to itself (which staggered start: ocean_launch.h)
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
-    static const char* const ramp_env = getenv("OCEAN_START_RAMP");             // 0 = never stagger the start of a serial frame's workgroups
-    if (ramp_env && atoi(ramp_env) == 0) stream_maps &= ~16;
     static const char* const stream_env = getenv("OCEAN_STREAM_MAPS");          // bit mask of the store policies
     if (stream_env) stream_maps = (atoi(stream_env) & 7) | (stream_maps & 24);
 #endif

@@ -41,10 +41,22 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb_b = xpass_height_groups<N, C>(), nb = (HF::NU + C - 1) / C;
-    // Staggered start (ocean_kernels.h: start_ramp_wait) for the one frame it was measured to pay for: a frame that has the device to itself
-    // (bit 4 of stream_maps: a serial frame), one 2048^2 tile, all seven fields, fp32 intermediates -- every launch one resident round.
+    // Staggered start (ocean_kernels.h: start_ramp_wait) for the frames it was measured to pay for: one 2048^2 tile, all seven fields, fp32
+    // intermediates, the usual form of the spectrum -- every launch one resident round.  A serial frame (bit 4 of stream_maps: it has the device to
+    // itself): z pass 5.0 us, normal-map workgroups and displacement pass 4.5 us; a pipelined frame, whose launches run beside the same launches
+    // of the other chains (profiles/r04_zpass_experiments.txt items 9-11): 5.0 / 9.0 / 9.0 us.
     const bool fast = !a.h0h && a.omega_q;       // the usual form of the spectrum: fp32 h0, 16-bit dispersion
-    const bool ramp = N == 2048 && tiles == 1 && (stream_maps & 16) && a.mode == 0 && !(stream_maps & 8) && fast;
+    const bool ramp = N == 2048 && tiles == 1 && a.mode == 0 && !(stream_maps & 8) && fast;
+    const bool alone = (stream_maps & 16) != 0;
+    int ramp_z = ramp ? 500 : 0, ramp_b = ramp ? (alone ? 450 : 900) : 0, ramp_d = ramp_b;
+#ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
+    {   static const char* const rz = getenv("OCEAN_RAMP_Z"); static const char* const rb = getenv("OCEAN_RAMP_B"); static const char* const rd = getenv("OCEAN_RAMP_D");
+        static const char* const ra = getenv("OCEAN_RAMP_ANY");     // 1: every size and batch (fp32, seven fields)
+        const bool on = ramp || (ra && atoi(ra) == 1 && a.mode == 0 && !(stream_maps & 8) && fast);
+        if (rz && on) ramp_z = atoi(rz);
+        if (rb && on) ramp_b = atoi(rb);
+        if (rd && on) ramp_d = atoi(rd); }
+#endif
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     // Which forms of the z pass a tile size has (ocean_kernels.h).  ZW1: one column, two-transform batches (four-transform batches at 256 /
@@ -106,8 +118,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
         unsigned gx = zw2 ? N / 4 + 1 : N / 2 + 1;
         FrameArgs za = a;
-        // a serial frame of one 2048^2 tile: the single-transform form's 1025 workgroups are one resident round -- staggered start (start_ramp_wait)
-        za.start_ramp = (c1 && ramp) ? 500 : 0;
+        // one 2048^2 tile: the single-transform form's 1025 workgroups are one resident round -- staggered start (start_ramp_wait)
+        za.start_ramp = c1 ? ramp_z : 0;
 #if defined(OCEAN_STAMPS) || defined(OCEAN_DEVELOPER)
         if (const char* ev = getenv("OCEAN_DEBUG_ROWS_GRID")) gx = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
 #endif
@@ -159,7 +171,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.per_workgroup = C;
             li.lds_bytes = (uint32_t)(k == 1 ? lds_b : lds_m);
             li.flags = ((stream_maps & (k == 1 ? 1 : 2)) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
-                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | (ramp ? OCEAN_LAUNCH_STAGGERED_START : 0u);
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | ((k == 1 ? ramp_b : ramp_d) ? OCEAN_LAUNCH_STAGGERED_START : 0u);
         }
 #define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16, args)                                                          \
         do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, args);       \
@@ -174,14 +186,14 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         }
 #endif
         FrameArgs ba = a;
-        ba.start_ramp = ramp ? 450 : 0;     // over its normal-map workgroups (the height workgroups start at once)
+        ba.start_ramp = ramp_b;             // over its normal-map workgroups (the height workgroups start at once)
         if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true, ba);
         else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false, ba);
 #ifdef OCEAN_STAMPS
         arm(2);
 #endif
         FrameArgs da = a;
-        da.start_ramp = ramp ? 450 : 0;     // its 257 workgroups are one per CU: the same read-then-write burst
+        da.start_ramp = ramp_d;             // its 257 workgroups are one per CU: the same read-then-write burst
         if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true, da);
         else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false, da);
 #undef OCEAN_XPASS2
