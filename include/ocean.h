@@ -407,7 +407,7 @@ enum {
     OCEAN_LAUNCH_STAGGERED_START = 256   /* not a variant (same instantiation, same bits): the launch's workgroups, all resident
                                             at once, start spread over a few microseconds so that the early ones store while
                                             the late ones still load -- the three launches of a frame of one 2048^2 tile
-                                            (seven fields, fp32; serial and pipelined frames with ramps of their own)     */
+                                            (serial and pipelined frames with ramps of their own), nowhere else          */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

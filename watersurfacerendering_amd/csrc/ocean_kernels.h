@@ -988,9 +988,10 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
 // any arithmetic takes 19.3 of the 22.2 us).  Spreading the workgroups' starts over a few microseconds -- workgroup i of G waits i / G of the
 // ramp, i in dispatch order -- lets the early ones store while the late ones still load.  Same box, interleaved, us: k_zpass_c1 23.0-23.4 ->
 // 21.9-22.4 with 5.0 us, k_xpass_disp 17.4-18.0 -> 16.1-16.4 with 4.5 us, k_xpass_b 20.2-20.4 -> 19.2-19.4 with 4.5 us over its NORMAL
-// workgroups alone (the height workgroups, which write next to nothing, all start at once; a ramp over all of them gains nothing); only the
-// serial frame of ONE 2048^2 tile gains (512^2, 1024^2: a loss; 4096^2 and batches -- several rounds, which overlap by themselves -- and
-// pipelined frames: nothing), so only that frame asks for it (ocean_launch.h).  profiles/r04_zpass_experiments.txt item 10.
+// workgroups alone (the height workgroups, which write next to nothing, all start at once; a ramp over all of them gains nothing).  Pipelined
+// frames, whose chains run in lockstep -- three such kernels side by side --, gain 1.2 us per frame with 5.0 / 9.0 / 9.0 us.  Only frames of
+// ONE 2048^2 tile gain (512^2, 1024^2: a loss; 4096^2 and batches -- several rounds, which overlap by themselves: nothing), in every mode and
+// precision, so only they ask for it (ocean_launch.h).  profiles/r04_zpass_experiments.txt items 10-12.
 __device__ __forceinline__ void start_ramp_wait(int ramp, unsigned idx, unsigned count)
 {
     if (ramp > 0) {
@@ -1103,7 +1104,7 @@ __global__ void __launch_bounds__(T, 6) k_zpass_c1(const FrameArgs a)
     const bool col0 = (nb == 0);
     const float h16s = a.h0h ? a.h0_inv_scale[tile] : 1.0f;
     const float base = a.omega_q ? a.base_freq[tile] : 0.0f;
-    if constexpr (FAST) start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (the launcher asks for it with the usual form of the spectrum only)
+    start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (one 2048^2 tile: ocean_launch.h)
     // phase 1 exactly as in k_zpass (zpass_load_pair / animate_with_mirror)
     spectrum_form<FAST>(a, [&](auto h16, auto w16) {
         constexpr bool H16 = decltype(h16)::value, W16 = decltype(w16)::value;
@@ -1383,7 +1384,7 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     // 0.3-0.5 us faster and stays.)
     const int nid = (int)blockIdx.x - HB;
     const int u0 = (N >= 2048 ? (nid == 0 ? NB - 1 : xcd_swizzle(nid - 1, NB - 1)) : xcd_swizzle(nid, NB)) * C;
-    if constexpr (!JAC && !Z16) start_ramp_wait(a.start_ramp, (unsigned)nid, (unsigned)NB);    // the NORMAL workgroups alone (the seven-field fp32 frame only: ocean_launch.h)
+    start_ramp_wait(a.start_ramp, (unsigned)nid, (unsigned)NB);    // the NORMAL workgroups alone (one 2048^2 tile: ocean_launch.h)
     constexpr size_t ESN = Z16 ? 4 : 8;
     const float2* __restrict__ z1 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + ((size_t)tile * HF::Z_TILE + HF::Z_GROUP) * ESN);
     const float2* __restrict__ z2 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(z1) + HF::Z_GROUP * ESN);
@@ -1533,7 +1534,7 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
 #endif
     constexpr int NB = (HF::NU + C - 1) / C;
     const int u0 = xcd_swizzle(blockIdx.x, NB) * C;
-    if constexpr (!JAC && !Z16) start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);   // (the seven-field fp32 frame only: ocean_launch.h)
+    start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);   // (one 2048^2 tile: ocean_launch.h)
     const float2* __restrict__ z0 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + (size_t)tile * HF::Z_TILE * (Z16 ? 4 : 8));
     [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;

@@ -41,18 +41,18 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb_b = xpass_height_groups<N, C>(), nb = (HF::NU + C - 1) / C;
-    // Staggered start (ocean_kernels.h: start_ramp_wait) for the frames it was measured to pay for: one 2048^2 tile, all seven fields, fp32
-    // intermediates, the usual form of the spectrum -- every launch one resident round.  A serial frame (bit 4 of stream_maps: it has the device to
-    // itself): z pass 5.0 us, normal-map workgroups and displacement pass 4.5 us; a pipelined frame, whose launches run beside the same launches
-    // of the other chains (profiles/r04_zpass_experiments.txt items 9-11): 5.0 / 9.0 / 9.0 us.
+    // Staggered start (ocean_kernels.h: start_ramp_wait) for the frames it was measured to pay for: ONE 2048^2 tile -- every launch one resident
+    // round --, every mode and precision.  A serial frame (bit 4 of stream_maps: it has the device to itself): z pass 5.0 us, normal-map workgroups
+    // and displacement pass 4.5 us; a pipelined frame, whose launches run beside the same launches of the other chains
+    // (profiles/r04_zpass_experiments.txt items 9-12): 5.0 / 9.0 / 9.0 us.
     const bool fast = !a.h0h && a.omega_q;       // the usual form of the spectrum: fp32 h0, 16-bit dispersion
-    const bool ramp = N == 2048 && tiles == 1 && a.mode == 0 && !(stream_maps & 8) && fast;
+    const bool ramp = N == 2048 && tiles == 1;
     const bool alone = (stream_maps & 16) != 0;
     int ramp_z = ramp ? 500 : 0, ramp_b = ramp ? (alone ? 450 : 900) : 0, ramp_d = ramp_b;
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
     {   static const char* const rz = getenv("OCEAN_RAMP_Z"); static const char* const rb = getenv("OCEAN_RAMP_B"); static const char* const rd = getenv("OCEAN_RAMP_D");
-        static const char* const ra = getenv("OCEAN_RAMP_ANY");     // 1: every size and batch (fp32, seven fields)
-        const bool on = ramp || (ra && atoi(ra) == 1 && a.mode == 0 && !(stream_maps & 8) && fast);
+        static const char* const ra = getenv("OCEAN_RAMP_ANY");     // 1: every size and batch
+        const bool on = ramp || (ra && atoi(ra) == 1);
         if (rz && on) ramp_z = atoi(rz);
         if (rb && on) ramp_b = atoi(rb);
         if (rd && on) ramp_d = atoi(rd); }
