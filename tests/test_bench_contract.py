@@ -185,13 +185,13 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The roofline fractions of the committed default bench line (profiles/r04m_bench_default.json) can be recomputed from
-    the committed rocprofv3 summary (profiles/kernel_stats.json <- r04m_kernel_stats_2048_bench_depth1.csv) and the byte
+    """The roofline fractions of the committed default bench line (profiles/r04n_bench_default.json) can be recomputed from
+    the committed rocprofv3 summary (profiles/kernel_stats.json <- r04n_kernel_stats_2048_bench_depth1.csv) and the byte
     accounting of this file: every kernel within 8 % (two processes: the hardware queue a context's stream lands on moves a kernel by up
     to +-1 us, profiles/r03_bimodal_probe.txt section 4a -- 6 % of the 17 us displacement pass), nothing above 1, and the summaries
     regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    line = [l for l in open(os.path.join(prof, "r04m_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(prof, "r04n_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
@@ -212,7 +212,7 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r04m_kernel_stats_2048_bench_depth1.csv"))):
+    for row in csv.DictReader(open(os.path.join(prof, "r04n_kernel_stats_2048_bench_depth1.csv"))):
         m = re.search(r"(k_[a-z_0-9]+)<2048", row["Name"])
         name = m.group(1) if m else None
         if name and name.startswith("k_zpass"):          # the z pass's kernel forms (k_zpass, k_zpass_c1) are all the frame's first launch
