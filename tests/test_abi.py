@@ -29,6 +29,19 @@ def test_header_and_binding_list_agree(abi):
     assert declared_symbols() == sorted(abi.SYMBOLS)
 
 
+def test_header_enumerators_match_the_binding(abi):
+    """Every OCEAN_* enumerator of include/ocean.h that the ctypes binding names has the header's value, and the binding names all of the
+    launch flags, modes and error codes (a flag added on one side only -- OCEAN_LAUNCH_STAGGERED_START was the last one -- fails here)."""
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ocean.h")).read(), flags=re.S)
+    enums = {k: int(v) for k, v in re.findall(r"\b(OCEAN_[A-Z0-9_]+)\s*=\s*(-?\d+)", txt)}
+    assert len(enums) > 20
+    for name, value in enums.items():
+        if name.startswith(("OCEAN_LAUNCH_", "OCEAN_MODE_", "OCEAN_E_")) or name == "OCEAN_OK":
+            assert hasattr(abi, name), name
+        if hasattr(abi, name):
+            assert getattr(abi, name) == value, (name, getattr(abi, name), value)
+
+
 def test_library_exports_every_declared_symbol(abi):
     L = abi.lib()
     for s in declared_symbols():
