@@ -87,7 +87,9 @@ def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
     assert ref["kind"] == "port" and ref["unit"] == "frames/s" and ref["value"] > 0
     assert ref["cores"] >= 1 and "sample" in ref and ("FFTW not available" in ref["sample"] or ref["fft"] == "fftw3f")
     assert ref["host"]["nproc"] >= 1
-    assert strong["value"] > 0 and "work-shared" in strong["sample"]
+    # (the strongest candidate of THIS run: the oracle's own FFT work-shared by a team, or scipy's pocketfft with stage D shared out -- which one
+    #  wins depends on the host and on its load)
+    assert strong["value"] > 0 and ("work-shared" in strong["sample"] or "shared out" in strong["sample"])
     # `cores` is the USABLE CPU count (min of the affinity mask and the cgroup quota) -- the team the sample really ran
     # with -- and the host's logical CPU count stands beside it (round 3 printed cores = 256 next to a quota of 16)
     usable, quota, aff, nproc = bench.usable_cpus()
