@@ -484,6 +484,8 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
                             "mean over 200 frames of a pass of its own (independent of --steps / --warmup); rocprofv3 --kernel-trace "
                             "--stats of the same command: profiles/kernel_stats.json",
         "rocprof_launch_us": d.get("rocprof_launch_us"),
+        "rocprof_frac": (d["own_bytes_per_launch"] / (d["rocprof_launch_us"] * 1e-6) * 1e-9 / HBM_PEAK_GBPS) if d.get("rocprof_launch_us") else None,
+        "profiles_current": profiles_current,
         "regime": "serial frames (pipeline depth 1): every kernel has the GPU to itself",
         "kernels": kernels,
         "serial_us_per_step": serial_us_per_step,
@@ -505,35 +507,120 @@ def roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, depth, ms_per_step, 
     }
 
 
-def build_line(args, world, n, tiles, frames_per_s, ms_per_step, roofline, gather_obj, extra_obj, cpu, cpu_strong):
-    """The ONE JSON line (a dict) of a run: the contract's keys + roofline + cpu_baseline + gather + extra."""
-    return {
+def _sig(x, digits=6):
+    """Floats of the compact line carry `digits` significant digits (a 17-digit repr per number is what made the line outgrow the driver)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None                                   # strict JSON: no NaN / Infinity tokens
+    return float(f"{x:.{digits}g}")
+
+
+def _compact(obj, digits=6):
+    if isinstance(obj, dict):
+        return {k: _compact(v, digits) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_compact(v, digits) for v in obj]
+    return _sig(obj, digits)
+
+
+LINE_BYTES_MAX = 8192      # the final stdout line stays below this (the driver parsed 16.4 KB in round 3 and not 20.4 KB in round 4)
+SIDECAR = "bench_extra.json"
+
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launch_us", "rocprof_launch_us",
+                 "rocprof_frac", "algorithmic_bytes_per_launch", "frame_frac", "serial_frame_frac", "serial_us_per_step", "profiles_current")
+
+
+def compact_roofline(r):
+    """The roofline object of the stdout line: SURVEY.md 8d / the contract's keys for the dominant kernel, every kernel's duration and
+    fraction beside them, no prose (the byte model, the sources of every figure and the pipelined-regime counters are in the sidecar)."""
+    if not r:
+        return None
+    out = {k: r.get(k) for k in ROOFLINE_KEYS}
+    out["kernels"] = {k: {"launch_us": v["launch_us"], "frac": v["frac"], "rocprof_launch_us": v.get("rocprof_launch_us"),
+                          "bytes_per_texel": r["kernel_bytes_per_texel"].get(k), "traffic": v.get("traffic_bytes_per_launch")}
+                      for k, v in r["kernels"].items()}
+    return out
+
+
+def compact_cpu(c, keys=("value", "unit", "cores", "nproc", "kind", "fft", "sample")):
+    if not c:
+        return None
+    out = {k: c[k] for k in keys if k in c}
+    if "sample" in out:
+        out["sample"] = str(out["sample"])[:160]
+    return out
+
+
+def compact_gather(g):
+    if not g:
+        return None
+    if "error" in g:
+        return {"error": str(g["error"])[:200]}
+    out = {k: g.get(k) for k in ("ranks", "rccl_ranks_seen", "tile_size", "tiles_per_rank", "bytes_into_root_per_step", "root_copy_matches_local_maps")}
+    for k in ("compute_only", "compute_plus_gather_serial", "compute_gather_overlapped", "compute_gather_overlapped_half_maps"):
+        if isinstance(g.get(k), dict):
+            out[k + "_tiles_per_s"] = g[k].get("tiles_per_s")
+    return out
+
+
+def build_line(args, world, n, tiles, frames_per_s, ms_per_step, roofline, gather_obj, cpu, cpu_strong, timing=None, build_id=None):
+    """The ONE JSON line of stdout (a dict): the contract's keys + compact roofline / cpu_baseline / gather / timing objects -- numbers
+    and short labels only, < LINE_BYTES_MAX bytes.  Everything else this script measures goes to the sidecar (build_sidecar)."""
+    t = timing or {}
+    line = {
         "metric": "ocean frames/s (ComputeWaves, 7 fields -> displacement + normal map)",
         "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "prewarm_frames": args.prewarm, "warmup_frames_effective": args.prewarm + args.warmup,
-        "warmup_note": "`warmup` is the W of the command line; `prewarm_frames` more untimed frames run ahead of them (the device needs a "
-                       "few hundred frames to reach its steady state) -- warmup_frames_effective untimed frames in all; the roofline's per-kernel "
-                       "passes are separate runs of 200 frames each, independent of --steps / --warmup",
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"{tiles * world} x {n}x{n} tiles, {tiles} per GPU" if tiles * world > 1 else f"{n}x{n} tile") +
-                               ", FULL7 (7 real fields via 3.5 complex 2-D iFFTs), "
-                               f"{tiles} tile(s) per rank per step, reference default parameters" +
+                               ", FULL7, reference default parameters" +
                                (" = BASELINE config 5" if (n, tiles * world, world) == (1024, 64, 8) else ""),
-                   "tile_size": n, "tiles_per_rank": tiles, "seed": SEED, "dt": DT,
-                   "pipeline_depth": args.depth,
-                   "api": "ocean_compute_waves_async x steps, then ocean_synchronize (frames alternate between "
-                          f"{args.depth} independent chains, each with its own intermediates and map set)",
+                   "tile_size": n, "tiles_per_rank": tiles, "pipeline_depth": args.depth, "seed": SEED, "dt": DT,
                    "parallelism": f"tiles sharded 1 process per GPU x{world}, no data-path collective"},
         "gtexels_per_s": n * n * frames_per_s * 1e-9,
+        "prewarm_frames": args.prewarm,
+        "timing": {"statistic": "median of regions", "regions": t.get("regions"), "ms_per_step_median": t.get("ms_per_step_median"),
+                   "ms_per_step_mean": t.get("ms_per_step_mean"), "ms_per_step_p10": t.get("ms_per_step_p10"),
+                   "ms_per_step_p90": t.get("ms_per_step_p90")} if t else None,
+        "roofline": compact_roofline(roofline),
+        "cpu_baseline": compact_cpu(cpu),
+        "cpu_baseline_strong": compact_cpu(cpu_strong, keys=("value", "unit", "cores", "kind")),
+        "gather": compact_gather(gather_obj),
+        "kernel_source_sha16": kernel_source_sha16(),
+        "build_id": build_id,
+        "sidecar": SIDECAR,
+    }
+    return _compact(line)
+
+
+def build_sidecar(line, args, roofline, gather_obj, extra_obj, cpu, cpu_strong, timing):
+    """Everything measured beside the headline, with the prose that explains each figure: written to SIDECAR next to this script and
+    echoed on stderr -- never part of the stdout line."""
+    return {
+        "line": line,
+        "warmup_note": "`warmup` is the W of the command line; `prewarm_frames` more untimed frames run ahead of them (the device needs a "
+                       "few hundred frames to reach its steady state); the roofline's per-kernel passes are separate runs of 200 frames "
+                       "each, independent of --steps / --warmup",
+        "warmup_frames_effective": args.prewarm + args.warmup,
+        "api": "ocean_compute_waves_async x steps, then ocean_synchronize (frames alternate between "
+               f"{args.depth} independent chains, each with its own intermediates and map set)",
+        "timing": timing,
         "roofline": roofline,
         "cpu_baseline": cpu,
         "cpu_baseline_strong": cpu_strong,
-        "speedup_vs_cpu_baseline_strong": (frames_per_s / cpu_strong["value"]) if cpu_strong and cpu_strong.get("value") else None,
+        "speedup_vs_cpu_baseline_strong": (line["value"] / cpu_strong["value"]) if cpu_strong and cpu_strong.get("value") else None,
         "gather": gather_obj,
         "extra": extra_obj,
     }
 
+
+def encode_line(line) -> bytes:
+    """Strict JSON (no NaN / Infinity), one line, below LINE_BYTES_MAX: anything else is a bug of this script, not something to emit."""
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if "\n" in text or len(text) >= LINE_BYTES_MAX:
+        raise RuntimeError(f"bench.py: the stdout line has {len(text)} bytes (limit {LINE_BYTES_MAX})")
+    return (text + "\n").encode()
 
 
 def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend, red_dev, barrier):
@@ -619,8 +706,8 @@ def main():
     args = parse(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.regions < 1:
-        raise SystemExit("--regions must be >= 1")
+    if args.regions < 7:
+        raise SystemExit("--regions must be >= 7 (ms_per_step is the median region, p10 / p90 beside it)")
     if args.cpu_baseline_child:                     # no GPU, no torch: just the oracle on the host cores
         ref, strong = cpu_baseline(args.size, args.cpu_seconds)
         check = None
@@ -705,6 +792,7 @@ def main():
     frames_per_s = world * tiles * args.steps / elapsed
     timing_stats = {"regions": args.regions, "steps_per_region": args.steps, "statistic": "median over the regions",
                     "ms_per_step_median": ms_per_step,
+                    "ms_per_step_mean": float(reg.mean()) / args.steps * 1e3,
                     "ms_per_step_p10": float(_np.percentile(reg, 10)) / args.steps * 1e3,
                     "ms_per_step_p90": float(_np.percentile(reg, 90)) / args.steps * 1e3,
                     "ms_per_step_min": float(reg[0]) / args.steps * 1e3, "ms_per_step_max": float(reg[-1]) / args.steps * 1e3,
@@ -745,22 +833,28 @@ def main():
     gather = None
     emitted = [False]
 
-    def emit(line_obj):
-        """rank 0: the ONE JSON line, through the saved stdout descriptor; at most once"""
+    def emit(line_obj, sidecar_obj=None):
+        """rank 0: the sidecar (file beside this script + stderr), then the ONE JSON line through the saved stdout descriptor; at most once"""
         if rank != 0 or emitted[0]:
             return
         emitted[0] = True
         import ctypes
-        sys.stdout.flush()
+        data = encode_line(line_obj)
+        if sidecar_obj is not None:
+            text = json.dumps(sidecar_obj, indent=1, default=str)
+            try:
+                with open(os.path.join(ROOT, SIDECAR), "w") as f:
+                    f.write(text + "\n")
+            except OSError as exc:                    # a read-only checkout: stderr still carries it
+                print(f"bench.py: could not write {SIDECAR}: {exc}", file=sys.stderr)
+            print("bench.py sidecar (" + SIDECAR + "):\n" + text, file=sys.stderr)
+        sys.stdout.flush(); sys.stderr.flush()
         ctypes.CDLL(None).fflush(None)            # C stdio buffers (the RCCL banner) leave through the redirected descriptor
-        os.write(json_fd, (json.dumps(line_obj) + "\n").encode())
+        os.write(json_fd, data)
 
     def headline(gather_obj, extra_obj, cpu, cpu_strong):
-        line = build_line(args, world, n, tiles, frames_per_s, ms_per_step, roofline, gather_obj, extra_obj, cpu, cpu_strong)
-        line["timing"] = timing_stats
-        line["p10_ms_per_step"] = timing_stats["ms_per_step_p10"]
-        line["p90_ms_per_step"] = timing_stats["ms_per_step_p90"]
-        return line
+        line = build_line(args, world, n, tiles, frames_per_s, ms_per_step, roofline, gather_obj, cpu, cpu_strong, timing_stats, build_id)
+        return line, build_sidecar(line, args, roofline, gather_obj, extra_obj, cpu, cpu_strong, timing_stats)
 
     # Everything the contract asks for is measured by now.  What follows at N > 1 -- the gather over xGMI, which no machine
     # available to the builder could run -- must not be able to take the line down with it: if it has not come back after
@@ -771,7 +865,7 @@ def main():
 
         def give_up():
             # the line goes out (the timed region is complete), but the run FAILED: launcher and driver must see it
-            emit(headline({"error": "the gather measurement did not finish within 240 s; timed region unaffected"}, {}, None, None))
+            emit(*headline({"error": "the gather measurement did not finish within 240 s; timed region unaffected"}, {}, None, None))
             os._exit(3)
         watchdog = threading.Timer(240.0, give_up)
         watchdog.daemon = True
@@ -786,7 +880,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
 
-    out = None
+    out = (None, None)
     if rank == 0:
         extra = {}
         if not args.no_extra and world == 1:
@@ -840,7 +934,7 @@ def main():
                             extra[key]["error_vs_float64_oracle"] = check["variants"][var]["max_err_over_max_channel"]
                             extra[key]["stated_tolerance"] = 1e-5 if var == "fp32" else 1e-3
         out = headline(gather, extra, cpu, cpu_strong)
-    emit(out)
+    emit(*out)
     failed = isinstance(gather, dict) and "error" in gather
     if world > 1:
         import threading

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 3   /* 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
+#define OCEAN_ABI_VERSION 4   /* 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
                                  ocean_set_frame_tracking, ocean_last_launch, ocean_export_maps, ocean_bind_output_dmabuf, ocean_select_streams,
                                  ocean_comm_count, ocean_algorithmic_bytes_per_launch (additions only) */
 
@@ -68,6 +68,10 @@ void ocean_default_params(ocean_params* p);
 
 const char* ocean_strerror(int code);
 int         ocean_abi_version(void);
+/* Content hash of the sources this library was built from (first 16 hex digits of the SHA-256 over the Makefile, the headers and the .hip
+ * files of csrc/ in name order, include/ocean.h, then the build's extra definitions): the loader compares it with the hash of the sources beside it and
+ * rebuilds on a mismatch, whatever the file times say (watersurfacerendering_amd/_abi.py: build); bench.py prints it.                    */
+const char* ocean_build_id(void);
 /* hipError_t value of the most recent failing HIP call on this thread (0 if none). */
 int         ocean_last_hip_error(void);
 
@@ -186,6 +190,11 @@ int ocean_read_maps_staging(ocean_t* ctx, uint32_t tile, void* mapped_base, size
  * ocean_synchronize / ocean_wait_frame / ocean_compute_waves, which -- from this
  * call on, until the maps are re-allocated -- synchronise the stream.            */
 int ocean_device_maps(ocean_t* ctx, void** d_disp, void** d_nrm);
+/* Whether somebody the context's streams do not order may read the internal maps (see ocean_wait_frame): set by ocean_export_maps and
+ * ocean_device_maps, cleared when the maps are re-allocated -- and by this call.  on = 0 is the caller's statement that every consumer of
+ * the handed-out pointers runs on ocean_stream() (or orders itself with events): ocean_wait_frame / ocean_compute_waves go back to the
+ * completion-record poll.  on != 0 forces the stream synchronisation for a context that shares its maps by means the library cannot see. */
+int ocean_set_external_readers(ocean_t* ctx, int on);
 
 /* Export of the maps as a dma-buf (the remainder: the reference uploads both maps every frame through a
  * host-visible staging buffer -- CopyModelTessDataToStagingBuffer + UpdateFrameMaps, WaterSurfaceMesh.cpp:642-755,
@@ -367,6 +376,12 @@ int ocean_last_rccl_error(void);
  * the context's.  OCEAN_E_UNSUPPORTED with a caller-owned stream (ocean_set_stream) and with caller-bound or imported output (the
  * calibration frames must not land in memory somebody else owns).  Results of frames are unaffected: bit-identical.               */
 int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [4] or NULL */);
+/* Staggered start of a frame's launches (one 2048 x 2048 tile; ocean_kernels.h: start_ramp_wait): workgroup i of a launch whose grid is ONE
+ * resident round waits i / G of a few microseconds before its first load, so that the early workgroups store while the late ones still load
+ * (-5 % on a serial frame, -2.5 % on pipelined ones).  The library applies it only where every workgroup of the launch is resident at once on
+ * THIS device (grid <= compute units x workgroups per unit); on != 0 (default) allows it, 0 switches it off for the context -- for a device
+ * shared with other work, where a workgroup's wait is simply lost.  Frames are bit-identical either way.                                    */
+int ocean_set_start_ramp(ocean_t* ctx, int on);
 
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */

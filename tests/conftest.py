@@ -2,7 +2,6 @@ import functools
 import os
 import subprocess
 import sys
-import warnings
 
 import pytest
 
@@ -35,29 +34,28 @@ def pytest_collection_modifyitems(config, items):
 def isolated(fn):
     """Run a GPU test in a pytest process of its own.
 
-    For the tests that share device memory between processes (dma-buf export / import) or drive the device out of memory: on this
-    pool the HIP runtime now and then abort()s -- silently, inside a later, unrelated runtime call (a read-out, a prepare) of the process
-    that exported, imported or exhausted memory: 3 of ~20 sessions in round 4, never under a debugger hook, never when such a test ran
-    alone -- and an abort takes the whole pytest session with it.  In its own process the test checks exactly what it checked before;
-    a child that DIES FROM A SIGNAL inside the runtime (not one that fails an assertion) is run once more and reported with a warning,
-    a second death fails the test.  The session's other tests never touch inter-process memory and are not exposed.
-    (tools/abort_hunt.sh runs the sessions un-isolated again, with the interpreter's fault handler and the runtime's error log: 14 full sessions and
-    15 of tests/test_api_state_gpu.py alone on one box at the end of round 4, no abort -- it depends on the box, and stays unexplained.)"""
+    For the tests that share device memory between processes (dma-buf export / import) or drive the device out of memory: they change
+    process-wide state of the HIP runtime (imported memory objects, a failed 8 TB allocation) that the session's other tests have no
+    business inheriting, and a crash of the runtime in one of them must be attributed to THAT test.  In its own process the test checks
+    exactly what it checked before.  A child that dies from a signal FAILS the test at once, with the interpreter's fault-handler
+    traceback and the child's output attached -- it is never run again (round 4 re-ran it once and only warned: an intermittent silent
+    abort() of the runtime, 3 of ~20 sessions on some boxes, was thereby retried away; INTEGRATION.md, known issues).
+    OCEAN_TEST_SIGNAL_XFAIL=1 reports such a death as a non-strict xfail instead (for a box known to show the runtime issue); nothing
+    sets it by default.  tools/abort_hunt.sh runs the sessions un-isolated for a hunt."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         if os.environ.get("OCEAN_TEST_CHILD") == "1":
             return fn(*args, **kwargs)
         node = os.path.relpath(fn.__code__.co_filename, ROOT) + "::" + fn.__name__
-        cmd = [sys.executable, "-m", "pytest", node, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"]
+        cmd = [sys.executable, "-X", "faulthandler", "-m", "pytest", node, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"]
         env = dict(os.environ, OCEAN_TEST_CHILD="1")
-        for attempt in (1, 2):
-            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-            if r.returncode == 0:
-                assert " passed" in r.stdout, r.stdout[-2000:]          # (really ran: not deselected, not skipped)
-                return
-            died = r.returncode < 0 or r.returncode in (134, 139)
-            if died and attempt == 1:
-                warnings.warn(f"{node}: the child process died inside the runtime (status {r.returncode}); running it once more")
-                continue
-            pytest.fail(f"{node} in its own process: status {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-2000:]}", pytrace=False)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0:
+            assert " passed" in r.stdout, r.stdout[-2000:]          # (really ran: not deselected, not skipped)
+            return
+        died = r.returncode < 0 or r.returncode in (134, 139)
+        report = f"{node} in its own process: status {r.returncode}{' (died from a signal)' if died else ''}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+        if died and os.environ.get("OCEAN_TEST_SIGNAL_XFAIL") == "1":
+            pytest.xfail(report)
+        pytest.fail(report, pytrace=False)
     return wrapper

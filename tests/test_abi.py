@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol(abi):
 
 def test_abi_version_defaults_and_strerror(abi):
     L = abi.lib()
-    assert L.ocean_abi_version() == 3
+    assert L.ocean_abi_version() == 4
     p = abi.Params()
     L.ocean_default_params(C.byref(p))
     # WSTessendorf.h:36-43,181
@@ -95,7 +95,42 @@ def test_argument_checking_without_device(abi):
     assert L.ocean_comm_destroy(None) == abi.OCEAN_E_INVALID
     assert L.ocean_gather_maps(None, 0, None, None) == abi.OCEAN_E_INVALID
     assert L.ocean_gather_maps_f16(None, 0, None, None) == abi.OCEAN_E_INVALID
+    assert L.ocean_set_external_readers(None, 0) == abi.OCEAN_E_INVALID
+    assert L.ocean_set_start_ramp(None, 0) == abi.OCEAN_E_INVALID
     L.ocean_destroy(None)
+
+
+def test_build_is_content_addressed(abi, tmp_path, monkeypatch):
+    """build() decides by CONTENT (the id embedded in the library against the hash of the sources beside it), never by file
+    times -- after an rsync or a checkout they mean nothing.  The id is read from the file's bytes (no dlopen of a possibly stale
+    library); a stale library with a NEWER time stamp is found stale, a fresh one with an OLDER time stamp is not rebuilt."""
+    want = abi.source_build_id()
+    assert len(want) == 16 and abi.library_build_id() == want == abi.lib().ocean_build_id().decode()
+    # the Makefile computes the same id (what the compile embeds)
+    out = subprocess.run(["make", "-s", "-C", abi.CSRC, "--eval", "print-id: ; @echo $(BUILD_ID)", "print-id"], capture_output=True, text=True)
+    assert out.stdout.strip() == want, (out.stdout, out.stderr)
+    # a library built from other sources, however new its time stamp: stale (make is not run here: the decision is what is tested)
+    calls = []
+    monkeypatch.setattr(abi.subprocess, "run", lambda cmd, **kw: calls.append(cmd) or subprocess.CompletedProcess(cmd, 0))
+    fake = tmp_path / "libocean_hip.so"
+    data = open(abi.LIB_PATH, "rb").read()
+    i = data.find(b"OCEAN_BUILD_ID:" + want.encode())
+    assert i >= 0
+    fake.write_bytes(data[:i] + b"OCEAN_BUILD_ID:" + b"0" * 16 + data[i + 31:])
+    os.utime(fake, (2e9, 2e9))                                 # far in the future: newer than every source
+    monkeypatch.setattr(abi, "_BUILT_LIB", str(fake))
+    assert abi.library_build_id() == "0" * 16
+    with pytest.raises(RuntimeError):                          # (the fake make changes nothing, so build() ends by saying so)
+        abi.build()
+    assert calls and calls[0][0] == "make" and "-B" in calls[-1]      # incremental first, then from scratch
+    # the real library with a time stamp OLDER than every source: up to date, no compile
+    calls.clear()
+    old = tmp_path / "old.so"
+    old.write_bytes(data)
+    os.utime(old, (1.0, 1.0))
+    monkeypatch.setattr(abi, "_BUILT_LIB", str(old))
+    abi.build()
+    assert not calls and "no compile" in abi.last_build and want in abi.last_build
 
 
 def test_no_cpu_fallback_when_no_gpu(abi):

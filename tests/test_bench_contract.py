@@ -44,6 +44,68 @@ def test_roofline_object_uses_own_bytes_and_never_exceeds_peak_on_them(bench):
     assert set(r["kernels"]) == set(names)
 
 
+def _full_run(bench, argv=()):
+    """A fully populated run as bench.py's main() assembles it: every object the stdout line and the sidecar are built from."""
+    a = bench.parse(list(argv))
+    names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
+    n, tiles = a.size, a.tiles
+    roof = bench.roofline_object(n, tiles, names, [0.0221234567, 0.0200345678, 0.0166456789], [0.0349, 0.0492, 0.0349], a.depth, 0.0498765432, 58.123456789, 73.0,
+                                 dict(zip(names, (23, 28, 22))))
+    cpu = {"value": 22.643211234, "unit": "frames/s", "cores": 16, "nproc": 256, "kind": "port", "fft": "own", "cores_note": "x" * 300,
+           "sample": "20 frames of the same 2048x2048 7-field workload after 2 warm-up frames, median (44.2 ms/frame); FFTW not available on this host: " + "y" * 400,
+           "stage_ms_of_the_median_frame": {"spectra": 1.0, "fft": 40.0, "pack": 2.0, "normalise": 1.2}, "gtexels_per_s": 0.0949, "host": {"cpu_model": "z" * 60, "nproc": 256},
+           "config1_256x256_height_only_cpu_ms": 0.9}
+    strong = dict(cpu, value=66.6123456789, cores=64, candidates_ms_per_frame={f"candidate {i} " + "c" * 80: 15.0 + i for i in range(10)})
+    gather = {"what": "w" * 400, "transport": "RCCL", "tile_size": 1024, "tiles_per_rank": 8, "ranks": 8, "rccl_ranks_seen": 8, "rccl_rank_of_root": 0,
+              "bytes_per_rank_per_step": 268435456, "bytes_into_root_per_step": 1879048192,
+              "compute_only": {"ms_per_step": 0.118, "tiles_per_s": 5.4e5}, "compute_plus_gather_serial": {"ms_per_step": 3.9, "tiles_per_s": 1.6e4},
+              "compute_gather_overlapped": {"ms_per_step": 3.6, "tiles_per_s": 1.78e4},
+              "compute_gather_overlapped_half_maps": {"ms_per_step": 1.9, "tiles_per_s": 3.4e4, "what": "h" * 100},
+              "root_ingest_GBps_overlapped": 522.123, "root_copy_matches_local_maps": True}
+    timing = {"regions": 9, "steps_per_region": a.steps, "statistic": "median over the regions", "ms_per_step_median": 0.0498765432, "ms_per_step_mean": 0.0501,
+              "ms_per_step_p10": 0.0484, "ms_per_step_p90": 0.0504, "ms_per_step_min": 0.048, "ms_per_step_max": 0.052,
+              "ms_per_step_of_each_region_in_order": [0.05] * 9, "what": "t" * 300}
+    extra = {f"configuration_{i}": {"size": 512, "us_per_step": 16.5 + i, "what": "e" * 200, "kernel_us": {k: 5.0 for k in names}} for i in range(24)}
+    return a, names, roof, cpu, strong, gather, timing, extra
+
+
+def test_stdout_line_is_compact_strict_json_and_the_rest_goes_to_the_sidecar(bench):
+    """the driver stopped parsing the line when it grew to 20.4 KB (16.4 KB still parsed).  The stdout line carries the
+    contract's keys with compact roofline / cpu_baseline / gather / timing objects -- below 8 KB with every measurement populated, strict JSON --
+    and everything else (extra, per-kernel tables, every note) goes to bench_extra.json + stderr."""
+    for argv, world in (((), 1), (("--gpus", "8", "--size", "1024", "--tiles", "8", "--depth", "2"), 8)):
+        a, names, roof, cpu, strong, gather, timing, extra = _full_run(bench, argv)
+        line = bench.build_line(a, world, a.size, a.tiles, 20052.123456789, 0.0498765432, roof, gather, cpu, strong, timing, "a5cbb90d78459412")
+        data = bench.encode_line(line)
+        assert data.endswith(b"\n") and data.count(b"\n") == 1 and len(data) < bench.LINE_BYTES_MAX == 8192
+        assert len(data) < 4096, len(data)                     # (in practice about 3 KB: room for the driver's 8 KB tail as well)
+        back = json.loads(data, parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+        assert back == line
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                    "roofline", "cpu_baseline"):
+            assert key in back, key
+        assert "extra" not in back and set(back["config"]) >= {"workload", "tile_size", "tiles_per_rank", "pipeline_depth"}
+        r = back["roofline"]
+        assert set(r) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_us", "rocprof_launch_us", "frame_frac", "serial_frame_frac", "kernels"}
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-5)
+        assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "nproc", "kind", "fft", "sample"} and len(back["cpu_baseline"]["sample"]) <= 160
+        assert back["cpu_baseline_strong"]["value"] == pytest.approx(66.6123, rel=1e-4)
+        assert back["gather"]["rccl_ranks_seen"] == 8 and back["gather"]["compute_gather_overlapped_tiles_per_s"] == pytest.approx(1.78e4)
+        assert back["timing"]["ms_per_step_p10"] <= back["ms_per_step"] <= back["timing"]["ms_per_step_p90"] and back["timing"]["regions"] == 9
+        assert back["sidecar"] == bench.SIDECAR and back["build_id"] == "a5cbb90d78459412" and len(back["kernel_source_sha16"]) == 16
+        side = bench.build_sidecar(line, a, roof, gather, extra, cpu, strong, timing)
+        assert side["line"] == line and side["extra"] == extra and side["roofline"]["kernels"] and "bytes_model" in side["roofline"]
+        assert side["cpu_baseline"]["host"] and side["speedup_vs_cpu_baseline_strong"] == pytest.approx(20052.1 / 66.6123, rel=1e-4)
+        json.dumps(side)
+    # non-finite numbers never reach the line as NaN / Infinity tokens
+    a, names, roof, cpu, strong, gather, timing, extra = _full_run(bench)
+    line = bench.build_line(a, 1, 2048, 1, float("nan"), float("inf"), roof, None, cpu, None, timing)
+    assert line["value"] is None and line["ms_per_step"] is None and b"NaN" not in bench.encode_line(line)
+    # an oversized line is a bug of the script, not something to emit
+    with pytest.raises(RuntimeError):
+        bench.encode_line(dict(line, junk="j" * 9000))
+
+
 def test_multi_gpu_line_carries_config5_workload_cpu_baseline_and_roofline(bench):
     """What rank 0 prints at N > 1: the documented config-5 invocation names the workload as BASELINE does,
     and the line keeps `cpu_baseline` and `roofline` (round 2 dropped both at N > 1)."""
@@ -53,19 +115,19 @@ def test_multi_gpu_line_carries_config5_workload_cpu_baseline_and_roofline(bench
                                  dict(zip(names, (23, 28, 22))))
     cpu = {"value": 20.0, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "synthetic"}
     gather = {"ranks": 8, "rccl_ranks_seen": 8, "compute_only": {"tiles_per_s": 5e5}}
-    line = bench.build_line(a, 8, 1024, 8, 5.6e5, 0.11, roof, gather, {}, cpu, dict(cpu, value=80.0))
+    line = bench.build_line(a, 8, 1024, 8, 5.6e5, 0.11, roof, gather, cpu, dict(cpu, value=80.0))
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32"
     assert line["config"]["workload"].startswith("64 x 1024x1024 tiles, 8 per GPU") and "BASELINE config 5" in line["config"]["workload"]
     assert line["config"]["tiles_per_rank"] == 8 and line["config"]["pipeline_depth"] == 2
     assert line["cpu_baseline"]["value"] == 20.0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline_strong"]["value"] == 80.0
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["kernel"] in names
-    assert r["algorithmic_bytes_per_launch"] == r["kernel_bytes_per_texel"][r["kernel"]] * 1024 * 1024 * 8
-    assert line["gather"]["rccl_ranks_seen"] == 8
-    assert line["warmup"] == 20 and line["warmup_frames_effective"] == 20 + a.prewarm
-    json.dumps(line)
+    assert r["algorithmic_bytes_per_launch"] == r["kernels"][r["kernel"]]["bytes_per_texel"] * 1024 * 1024 * 8
+    assert line["gather"]["rccl_ranks_seen"] == 8 and line["gather"]["compute_only_tiles_per_s"] == 5e5
+    assert line["warmup"] == 20 and line["prewarm_frames"] == a.prewarm
+    bench.encode_line(line)
     # a single-GPU single-tile line still names the headline tile
-    one = bench.build_line(bench.parse([]), 1, 2048, 1, 2e4, 0.05, roof, None, {}, cpu, None)
+    one = bench.build_line(bench.parse([]), 1, 2048, 1, 2e4, 0.05, roof, None, cpu, None)
     assert one["config"]["workload"].startswith("2048x2048 tile")
 
 
@@ -79,7 +141,8 @@ def test_stale_profile_summaries_are_not_quoted(bench, monkeypatch):
     assert (r["traffic"] is not None) == current
     monkeypatch.setattr(bench, "kernel_source_sha16", lambda: "0" * 16)
     r = bench.roofline_object(2048, 1, names, [0.025, 0.022, 0.0175], None, 1, 0.066, 66.0, 73.0)
-    assert r["traffic"] is None and r["rocprof_launch_us"] is None and all("traffic_bytes_per_launch" not in k for k in r["kernels"].values())
+    assert r["traffic"] is None and r["rocprof_launch_us"] is None and r["rocprof_frac"] is None and all("traffic_bytes_per_launch" not in k for k in r["kernels"].values())
+    assert bench.compact_roofline(r)["profiles_current"] is False
 
 
 def test_cpu_baseline_leg_runs_and_reports_its_shape(bench):
@@ -106,12 +169,15 @@ def test_timed_regions_are_repeated_and_reported_as_median_with_spread(bench):
     assert a.regions >= 7
     assert bench.parse(["--regions", "11"]).regions == 11
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for key in ("ms_per_step_p10", "ms_per_step_p90", "ms_per_step_median", "steps_per_region", "p10_ms_per_step", "p90_ms_per_step"):
+    for key in ("ms_per_step_p10", "ms_per_step_p90", "ms_per_step_median", "ms_per_step_mean", "steps_per_region"):
         assert key in src
     names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
     roof = bench.roofline_object(2048, 1, names, [0.025, 0.022, 0.0175], None, 1, 0.066, 66.0, 73.0)
-    line = bench.build_line(a, 1, 2048, 1, 2e4, 0.05, roof, None, {}, None, None)
+    line = bench.build_line(a, 1, 2048, 1, 2e4, 0.05, roof, None, None, None)
     assert line["steps"] == a.steps and line["warmup"] == a.warmup and line["ms_per_step"] == 0.05
+    # fewer than seven regions have no p10 / p90 worth the name: refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--regions", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--regions must be >= 7" in r.stderr and "{" not in r.stdout
 
 
 def test_config4_check_compares_saved_gpu_rows_with_the_float64_oracle(bench, tmp_path):

@@ -29,17 +29,17 @@ OCEAN_MODE_FULL7, OCEAN_MODE_CHOPPY5, OCEAN_MODE_HEIGHT1, OCEAN_MODE_JACOBIAN = 
 
 #: every symbol include/ocean.h declares (tests check the .so exports each one)
 SYMBOLS = [
-    "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_last_hip_error",
+    "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_build_id", "ocean_last_hip_error",
     "ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_set_lambda",
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_frame_tracking", "ocean_set_time_offsets", "ocean_synchronize",
     "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
-    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_export_maps", "ocean_bind_output", "ocean_bind_output_dmabuf",
+    "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_set_external_readers", "ocean_export_maps", "ocean_bind_output", "ocean_bind_output_dmabuf",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_comm_count", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
     "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
     "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
-    "ocean_select_streams", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
+    "ocean_select_streams", "ocean_set_start_ramp", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
 ]
 
 OCEAN_LAUNCH_NT_MAPS, OCEAN_LAUNCH_NT_INTER, OCEAN_LAUNCH_HALF_INTER, OCEAN_LAUNCH_JACOBIAN = 1, 2, 4, 8
@@ -68,22 +68,56 @@ class LaunchInfo(C.Structure):
 
 last_build = ""      # what the most recent build() did, for the caller to log
 
+_ID_MARK = b"OCEAN_BUILD_ID:"
+
+
+def source_build_id(defs: str = "") -> str:
+    """Content hash of the library's sources, computed exactly as csrc/Makefile does (BUILD_ID): SHA-256 over Makefile, *.h, *.hip of
+    csrc/ in byte order of their names, then include/ocean.h, then the build's extra definitions; first 16 hex digits."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f == "Makefile" or (f.endswith((".h", ".hip")) and os.path.isfile(os.path.join(CSRC, f))))
+    for f in names:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"), "rb").read())
+    h.update(defs.encode())
+    return h.hexdigest()[:16]
+
+
+def library_build_id(path: str = None) -> str | None:
+    """The id embedded in a built library (ocean_build_id()), read from the file's bytes: no dlopen, so a stale library is never loaded
+    just to find out that it is stale.  None: no such file, or a library from before the id existed."""
+    path = path or _BUILT_LIB
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    i = data.find(_ID_MARK)
+    if i < 0:
+        return None
+    j = data.find(b"\0", i)
+    return data[i + len(_ID_MARK):j].decode("ascii", "replace")
+
 
 def build(force: bool = False) -> str:
-    """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  force (or OCEAN_FORCE_REBUILD=1 in
-    the environment) rebuilds every translation unit from scratch instead of trusting file times."""
+    """Compile libocean_hip.so for gfx950 with hipcc (cross-compiles without a GPU) unless the library beside the sources was built
+    from exactly these sources: the decision compares CONTENT hashes (ocean_build_id() against source_build_id()), never file times --
+    after an rsync or a checkout the times mean nothing.  force (or OCEAN_FORCE_REBUILD=1) rebuilds every translation unit."""
     force = force or os.environ.get("OCEAN_FORCE_REBUILD", "") not in ("", "0")
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h")) or f == "Makefile"]
-    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"))
-    newer = [] if not os.path.exists(_BUILT_LIB) else [s for s in srcs if os.path.getmtime(s) > os.path.getmtime(_BUILT_LIB)]
-    stale = (not os.path.exists(_BUILT_LIB)) or bool(newer)
+    want, have = source_build_id(), library_build_id()
     global last_build
-    if force or stale:
-        why = "forced" if force else ("no library yet" if not os.path.exists(_BUILT_LIB) else "sources newer than the library: " + ", ".join(os.path.basename(s) for s in newer))
-        subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
-        last_build = f"rebuilt libocean_hip.so ({why})"
-    else:
-        last_build = "libocean_hip.so is up to date with every source (no compile; OCEAN_FORCE_REBUILD=1 rebuilds from scratch)"
+    if not force and have == want:
+        last_build = f"libocean_hip.so carries build id {have} = the hash of the sources beside it (no compile; OCEAN_FORCE_REBUILD=1 rebuilds from scratch)"
+        return _BUILT_LIB
+    why = "forced" if force else ("no library yet" if have is None and not os.path.exists(_BUILT_LIB) else f"library build id {have} != source hash {want}")
+    subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
+    if library_build_id() != want:
+        # make trusted file times that lie (objects newer than sources they were not built from): everything from scratch
+        subprocess.run(["make", "-C", CSRC, "-B"], check=True, stdout=subprocess.DEVNULL)
+        why += "; incremental make left a stale library, rebuilt from scratch"
+    if library_build_id() != want:
+        raise RuntimeError(f"libocean_hip.so has build id {library_build_id()} after a full rebuild, sources hash to {want}")
+    last_build = f"rebuilt libocean_hip.so ({why}); build id {want}"
     return _BUILT_LIB
 
 
@@ -115,6 +149,7 @@ def lib() -> C.CDLL:
         "ocean_default_params": (None, [C.POINTER(Params)]),
         "ocean_strerror": (C.c_char_p, [i32]),
         "ocean_abi_version": (i32, []),
+        "ocean_build_id": (C.c_char_p, []),
         "ocean_last_hip_error": (i32, []),
         "ocean_create": (i32, [C.POINTER(P), u32, u32, i32]),
         "ocean_destroy": (None, [P]),
@@ -147,6 +182,7 @@ def lib() -> C.CDLL:
         "ocean_last_rccl_error": (i32, []),
         "ocean_device_maps": (i32, [P, C.POINTER(P), C.POINTER(P)]),
         "ocean_bind_output": (i32, [P, P, P]),
+        "ocean_set_external_readers": (i32, [P, i32]),
         "ocean_bind_output_dmabuf": (i32, [P, i32, C.c_size_t, C.c_size_t, C.c_size_t]),
         "ocean_export_maps": (i32, [P, C.POINTER(i32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32)]),
         "ocean_displace_grid": (i32, [P, u32, u32, f32, f32, f32]),
@@ -167,6 +203,7 @@ def lib() -> C.CDLL:
         "ocean_read_spectrum": (i32, [P, u32, C.c_void_p, C.c_void_p]),
         "ocean_read_xi": (i32, [P, u32, C.c_void_p]),
         "ocean_select_streams": (i32, [P, u32, FP]),
+        "ocean_set_start_ramp": (i32, [P, i32]),
         "ocean_time_frames": (i32, [P, f32, f32, i32, i32, FP, FP]),
         "ocean_kernel_name": (C.c_char_p, [P, i32]),
         "ocean_last_launch": (i32, [P, i32, C.POINTER(LaunchInfo)]),

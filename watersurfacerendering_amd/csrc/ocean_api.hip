@@ -194,6 +194,14 @@ const char* ocean_strerror(int code)
 }
 
 int ocean_abi_version(void) { return OCEAN_ABI_VERSION; }
+
+// Content hash of the sources (csrc/Makefile computes it and passes -DOCEAN_BUILD_ID); the marker in front lets the loader find the
+// string in the file without loading the library (watersurfacerendering_amd/_abi.py: library_build_id).
+#ifndef OCEAN_BUILD_ID
+#define OCEAN_BUILD_ID "unknown"
+#endif
+static const char g_build_id[] = "OCEAN_BUILD_ID:" OCEAN_BUILD_ID;
+const char* ocean_build_id(void) { return g_build_id + 15; }
 int ocean_last_hip_error(void) { return g_last_hip; }
 
 int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
@@ -477,8 +485,8 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set];
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
     a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
-    // the chain's sequence number and tracking state are committed only once the launches have succeeded: a failed enqueue leaves
-    // have_frame / last_set / seq describing the previous frame, whose records and maps are intact
+    // the chain's sequence number, tracking and burst state are committed only once the launches have succeeded; a failed enqueue
+    // invalidates the chain's frame (see below: part of its launches may have run)
     unsigned frame_seq = c->seq[set] + 1u;
     if (frame_seq == 0) frame_seq = 1;                  // never 0: a fresh record buffer reads as "no frame"
     a.frame_seq = frame_seq;
@@ -538,23 +546,34 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     // behind the z pass of frame k-1 (one event each).
     // Bursts of 20 / 100 / 1000 frames at 2048^2, depth 3: 52.6 / 49.6 / 47.9 -> 51.6 / 48.0 / 47.3 us per frame (tools/burst_probe.py;
     // chaining EVERY frame's z pass instead costs 8 us per frame: profiles/r04_zpass_experiments.txt item 5).
+    // (the burst state -- burst_pos, z_last_set -- is committed below, once the launches have succeeded; the stream wait enqueued here is
+    //  harmless if they do not: a wait for an event that has been recorded already)
     c->after_z = nullptr;
-    if (pipe) {
-        if (c->burst_pos < c->depth) {
-            if (!c->z_done[set]) HIP_TRY(hipEventCreateWithFlags(&c->z_done[set], hipEventDisableTiming));
-            if (c->z_last_set >= 0 && c->z_last_set != set && c->z_done[c->z_last_set]) HIP_TRY(hipStreamWaitEvent(st, c->z_done[c->z_last_set], 0));
-            c->after_z = c->z_done[set];
-            c->z_last_set = set;
-        }
-        if (c->burst_pos < MAXD + 1) c->burst_pos++;
+    const bool stagger = pipe && c->burst_pos < c->depth;
+    if (stagger) {
+        if (!c->z_done[set]) HIP_TRY(hipEventCreateWithFlags(&c->z_done[set], hipEventDisableTiming));
+        if (c->z_last_set >= 0 && c->z_last_set != set && c->z_done[c->z_last_set]) HIP_TRY(hipStreamWaitEvent(st, c->z_done[c->z_last_set], 0));
+        c->after_z = c->z_done[set];
     }
     hipError_t e = hipErrorInvalidValue;
     if (c->n <= 256) e = ocean_launch_frame_small(c, a, stream_maps, st, marks);
     else if (c->n <= 1024) e = ocean_launch_frame_mid(c, a, stream_maps, st, marks);
     else if (c->n == 2048) e = ocean_launch_frame_2048(c, a, stream_maps, st, marks);
     else if (c->n == 4096) e = ocean_launch_frame_4096(c, a, stream_maps, st, marks);
-    else return OCEAN_E_UNSUPPORTED;
-    if (e != hipSuccess) { g_last_hip = (int)e; return OCEAN_E_HIP; }
+    else { c->after_z = nullptr; return OCEAN_E_UNSUPPORTED; }
+    c->after_z = nullptr;
+    if (e != hipSuccess) {
+        // some of the frame's launches may have run: the chain's records, height keys and maps no longer describe ONE frame -- the chain has
+        // no frame until the next successful enqueue (wait / read-out: OCEAN_E_NOT_READY), the other chains are untouched
+        g_last_hip = (int)e;
+        c->seq[set] = 0;
+        if (c->last_set == set) c->have_frame = false;
+        return OCEAN_E_HIP;
+    }
+    if (pipe) {
+        if (stagger) c->z_last_set = set;
+        if (c->burst_pos < MAXD + 1) c->burst_pos++;
+    }
     c->seq[set] = frame_seq;
     c->tracked[set] = track;
     if (pipe) c->frame_ctr++;
@@ -755,6 +774,13 @@ int ocean_device_maps(ocean_t* c, void** d_disp, void** d_nrm)
     if (d_disp) *d_disp = c->ext_disp ? (void*)c->ext_disp : (void*)c->dispN[c->last_set];
     if (d_nrm) *d_nrm = c->ext_nrm ? (void*)c->ext_nrm : (void*)c->nrmN[c->last_set];
     c->maps_shared = true;              // somebody outside the context's streams may read the maps from now on: see wait_frame
+    return OCEAN_OK;
+}
+
+int ocean_set_external_readers(ocean_t* c, int on)
+{
+    if (!c) return OCEAN_E_INVALID;
+    c->maps_shared = on != 0;
     return OCEAN_OK;
 }
 
@@ -1077,6 +1103,13 @@ int ocean_set_pipeline_depth(ocean_t* c, int depth)
     HIP_TRY(hipSetDevice(c->device));
     SYNC_ALL(c);
     c->depth = depth;
+    return OCEAN_OK;
+}
+
+int ocean_set_start_ramp(ocean_t* c, int on)
+{
+    if (!c) return OCEAN_E_INVALID;
+    c->start_ramp = on != 0;
     return OCEAN_OK;
 }
 

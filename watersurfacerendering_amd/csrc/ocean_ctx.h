@@ -30,6 +30,7 @@ struct ocean_ctx {
     float dispersion_param = 0.0f;
     int last_set = 0;
     int cu_count = 0;               // compute units of the device
+    bool start_ramp = true;         // ocean_set_start_ramp: the staggered start may be used where it applies (ocean_launch.h)
     uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
     bool lambda_uniform = true;
     bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)

@@ -1087,8 +1087,10 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
 
 template <int N> constexpr size_t zpass_c1_lds_bytes() { return sizeof(c32) * fft_lds_elems<N, 1>() + sizeof(float) * N; }
 
+// (the instantiations that carry all four forms of the spectrum -- !FAST: fp16 copy, fp32 dispersion -- need a few registers more than the
+//  80 of six waves per SIMD and spilled 24-28 bytes per lane under that cap: they ask for five, 96 registers, no scratch)
 template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true>
-__global__ void __launch_bounds__(T, 6) k_zpass_c1(const FrameArgs a)
+__global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // one transform
@@ -1096,6 +1098,7 @@ __global__ void __launch_bounds__(T, 6) k_zpass_c1(const FrameArgs a)
     float* raw = reinterpret_cast<float*>(fbuf);                           // [0]: S-(0) of the column, until the first exchange
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
+    start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (one 2048^2 tile: ocean_launch.h) -- ahead of every load: nothing is live across the wait
     TwiddleRegs<N, 1, T, P> twr;
     twr.load(a.tw, tid);
     const int nb = xcd_swizzle((int)blockIdx.x, N / 2 + 1);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
@@ -1104,7 +1107,6 @@ __global__ void __launch_bounds__(T, 6) k_zpass_c1(const FrameArgs a)
     const bool col0 = (nb == 0);
     const float h16s = a.h0h ? a.h0_inv_scale[tile] : 1.0f;
     const float base = a.omega_q ? a.base_freq[tile] : 0.0f;
-    start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (one 2048^2 tile: ocean_launch.h)
     // phase 1 exactly as in k_zpass (zpass_load_pair / animate_with_mirror)
     spectrum_form<FAST>(a, [&](auto h16, auto w16) {
         constexpr bool H16 = decltype(h16)::value, W16 = decltype(w16)::value;

@@ -46,9 +46,15 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // and displacement pass 4.5 us; a pipelined frame, whose launches run beside the same launches of the other chains
     // (profiles/r04_zpass_experiments.txt items 9-12): 5.0 / 9.0 / 9.0 us.
     const bool fast = !a.h0h && a.omega_q;       // the usual form of the spectrum: fp32 h0, 16-bit dispersion
-    const bool ramp = N == 2048 && tiles == 1;
+    // ... and only where the launch IS one resident round on this device: every workgroup of the grid has a slot at once (compute units x
+    // workgroups per unit: six of the single-transform z pass -- 25.6 KB of LDS, launch bounds; five of its all-forms instantiations --, two of either x pass -- 70 KB of LDS);
+    // on a smaller or partitioned device the late workgroups would wait twice.  ocean_set_start_ramp(ctx, 0) switches it off altogether.
+    const bool ramp = N == 2048 && tiles == 1 && c->start_ramp;
     const bool alone = (stream_maps & 16) != 0;
-    int ramp_z = ramp ? 500 : 0, ramp_b = ramp ? (alone ? 450 : 900) : 0, ramp_d = ramp_b;
+    const unsigned cus = (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
+    int ramp_z = (ramp && (N / 2 + 1) <= (fast ? 6u : 5u) * cus) ? 500 : 0;
+    int ramp_b = (ramp && (hb_b + nb) <= 2u * cus) ? (alone ? 450 : 900) : 0;
+    int ramp_d = (ramp && nb <= 2u * cus) ? (alone ? 450 : 900) : 0;
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
     {   static const char* const rz = getenv("OCEAN_RAMP_Z"); static const char* const rb = getenv("OCEAN_RAMP_B"); static const char* const rd = getenv("OCEAN_RAMP_D");
         static const char* const ra = getenv("OCEAN_RAMP_ANY");     // 1: every size and batch
@@ -150,7 +156,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #undef OCEAN_ZPASS2
 #undef OCEAN_ZPASS3
         if (!launched) return hipErrorInvalidConfiguration;     // (a form this build does not carry: the rules above never ask for one)
-        if (c->after_z) (void)hipEventRecord(c->after_z, st);   // the first frames after a drain: the next chain's z pass starts behind this one (ocean_api.hip)
+        if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;   // the first frames after a drain: the next chain's z pass starts behind this one (ocean_api.hip)
     }
 #ifdef OCEAN_STAMPS
     if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
