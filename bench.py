@@ -753,6 +753,7 @@ def main():
 
     import watersurfacerendering_amd as W
     from watersurfacerendering_amd import dist as wdist
+    build_id = W._abi.lib().ocean_build_id().decode()      # content hash of the sources the loaded library was built from
 
     n, tiles = args.size, args.tiles
     first_tile, _ = wdist.tile_shard(tiles * world, world, rank)

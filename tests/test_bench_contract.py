@@ -289,3 +289,24 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
             a = acc.setdefault(name, [0, 0.0]); a[0] += int(row["Calls"]); a[1] += float(row["TotalDurationNs"])
     for k, (calls, total) in acc.items():
         assert abs(total / calls * 1e-3 - st[k + "@2048"]["avg_us"]) < 1e-6
+
+
+def test_bench_py_refers_to_no_undefined_global(bench):
+    """The GPU half of main() cannot run here; at least every name it (or any other function of the script) resolves at module level must
+    exist -- a name that is neither assigned in its function nor defined at module level nor a builtin is a NameError waiting for the GPU
+    box (round 5's first GPU run died of exactly that after the timed region)."""
+    import builtins
+    import symtable
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    top = symtable.symtable(src, "bench.py", "exec")
+    module_names = set(top.get_identifiers()) | set(dir(builtins)) | {"__file__", "__name__"}
+    missing = []
+
+    def walk(scope):
+        for sym in scope.get_symbols():
+            if sym.is_referenced() and sym.is_global() and sym.get_name() not in module_names:
+                missing.append((scope.get_name(), sym.get_name()))
+        for child in scope.get_children():
+            walk(child)
+    walk(top)
+    assert not missing, missing
