@@ -314,7 +314,11 @@ def test_bench_self_launcher_starts_n_ranks():
     # the N > 1 line keeps the CPU baseline (rank 0's host) and names the sharded workload (config 5's shape: T tiles per GPU)
     assert out["config"]["workload"].startswith("4 x 512x512 tiles, 2 per GPU") and out["config"]["tiles_per_rank"] == 2
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1
-    assert out["warmup"] == 5 and out["warmup_frames_effective"] == 25
+    assert out["warmup"] == 5 and out["prewarm_frames"] == 20
+    # the line is the compact one: a few KB, the detail in the sidecar beside the script
+    assert len(lines[0]) < 8192 and out["sidecar"] == "bench_extra.json"
+    side = json.load(open(os.path.join(root, out["sidecar"])))
+    assert side["line"] == out and side["warmup_frames_effective"] == 25 and side["roofline"]["kernels"]
 
 
 def test_readout_paths_under_pipelining_refer_to_the_last_frame():

@@ -513,6 +513,8 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.t = t;
     a.mode = c->mode;
     a.start_ramp = 0;       // (set per launch by the launcher where a staggered start pays: ocean_launch.h)
+    a.zmask = 15; a.xb_roles = 3;                   // (per launch: the launcher's frame order)
+    a.rec_mode = track ? 2 : 1;                     // what the frame's LAST launch does with the completion records
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
     const double texels = (double)c->tiles * (double)c->n * (double)c->n;
     // several frames in flight, or maps that would push everything else out of the 256 MiB memory-side cache anyway
@@ -1106,6 +1108,13 @@ int ocean_set_pipeline_depth(ocean_t* c, int depth)
     return OCEAN_OK;
 }
 
+int ocean_set_frame_order(ocean_t* c, int order)
+{
+    if (!c || order < OCEAN_ORDER_AUTO || order > OCEAN_ORDER_SPLIT) return OCEAN_E_INVALID;
+    c->frame_order = order;             // takes effect at the next frame
+    return OCEAN_OK;
+}
+
 int ocean_set_start_ramp(ocean_t* c, int on)
 {
     if (!c) return OCEAN_E_INVALID;
@@ -1195,12 +1204,12 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
         const int nsets = pipe ? c->depth : 1;
         double acc[3] = {0, 0, 0};
         long counted = 0;
-        auto collect = [&](int set) -> int {
-            HIP_TRY(hipEventSynchronize(c->mark_ev[set][5]));
-            for (int k = 0; k < 3; ++k) {
+        auto collect = [&](int set) -> int {       // (every frame of the pass has the same launches: c->launch_count / launch_kernel)
+            HIP_TRY(hipEventSynchronize(c->mark_ev[set][2 * c->launch_count - 1]));
+            for (int l = 0; l < c->launch_count; ++l) {
                 float m = 0.f;
-                HIP_TRY(hipEventElapsedTime(&m, c->mark_ev[set][2 * k], c->mark_ev[set][2 * k + 1]));
-                acc[k] += m;
+                HIP_TRY(hipEventElapsedTime(&m, c->mark_ev[set][2 * l], c->mark_ev[set][2 * l + 1]));
+                acc[c->launch_kernel[l]] += m;      // a kernel that runs twice per frame (split order) reports the sum
             }
             ++counted;
             return OCEAN_OK;

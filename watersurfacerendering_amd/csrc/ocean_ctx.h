@@ -11,6 +11,7 @@
 #include "ocean_kernels.h"
 
 constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
+constexpr int OCEAN_MAX_LAUNCHES = 5;   // launches per frame: three, or five in the split frame order (ocean_launch.h)
 
 struct ocean_ctx {
     uint32_t n = 0;
@@ -95,7 +96,10 @@ struct ocean_ctx {
     unsigned long long* stamps = nullptr;   // diagnostic builds only
     hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
     hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
-    hipEvent_t mark_ev[MAXD][6] = {};   // per-launch timing: (start, stop) of each of the three kernels of a frame
+    hipEvent_t mark_ev[MAXD][2 * OCEAN_MAX_LAUNCHES] = {};   // per-launch timing: (start, stop) of each launch of a frame
+    int launch_count = 3;               // launches of the most recent frame (3; 5 in the split order) and the kernel (0 z pass, 1 k_xpass_b,
+    int launch_kernel[OCEAN_MAX_LAUNCHES] = {0, 1, 2, 0, 1};   //   2 k_xpass_disp) each of them ran: ocean_time_frames sums a kernel's launches
+    int frame_order = 0;                // ocean_set_frame_order: 0 the library chooses, 1 standard, 2 split by output map (ocean_launch.h)
     ocean_launch_info last_launch[3] = {};  // what the most recent frame launched (ocean_last_launch)
     hipEvent_t z_done[MAXD] = {};       // pipelined frames right after a drain: recorded behind a chain's z pass (see enqueue_frame)
     hipEvent_t after_z = nullptr;       // what launch_frame records behind the z pass of the frame being enqueued (null: nothing)
@@ -121,7 +125,7 @@ inline hipStream_t stream_of(const ocean_ctx* c, int set) { return c->user ? c->
 // own translation unit (frames_*.hip) so that the library builds in parallel.  stream_maps: bit 0 normal map and
 // bit 1 displacement map stored non-temporally, bit 2 intermediates stored non-temporally, bit 3 half2 intermediates,
 // bit 4 the frame runs alone on the device (serial frames: the z pass may split its last round of columns).
-// marks: 6 events (start, stop per kernel) or null.
+// marks: 2 x OCEAN_MAX_LAUNCHES events (start, stop per launch) or null.
 hipError_t ocean_launch_frame_small(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);   // 16 .. 256
 hipError_t ocean_launch_frame_mid(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);     // 512, 1024
 hipError_t ocean_launch_frame_2048(ocean_ctx* c, const ocean::FrameArgs& a, int stream_maps, hipStream_t st, hipEvent_t* marks);

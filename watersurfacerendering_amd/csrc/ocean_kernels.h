@@ -172,6 +172,13 @@ struct FrameArgs {
                              // set per launch by ocean_launch.h, 0 in ocean_api.hip's arguments)
     int mode;                // 0 FULL7 (reference), 1 CHOPPY5 (dDx/dx = dDz/dz = 0), 2 HEIGHT1 (height only),
                              // 3 JACOBIAN (FULL7 + the cross derivative; displacement.w = Jacobian of the horizontal displacement)
+    // ---- set per launch by ocean_launch.h (ocean_api.hip leaves the defaults) ----
+    int zmask;               // z pass: the transforms this launch runs -- bit 0 pair 0, bit 1 pair 1, bit 2 pair 2, bit 3 the height (pair 3 in the
+                             // Jacobian mode).  15 = all (one z pass per frame); the split frame order (launch_frame) runs {height, pair 0} and
+                             // {pair 1, pair 2} as two launches, each animating the spectrum for itself
+    int xb_roles;            // k_xpass_b: bit 0 the HEIGHT workgroups, bit 1 the NORMAL workgroups (3 = both in one launch)
+    int rec_mode;            // completion records of this launch: 0 none, 1 block 0 writes them early (untracked frame: the stream tells when it
+                             // has finished), 2 the last workgroup to finish writes them (frame_done; tracked frame) -- the frame's LAST launch
 };
 
 
@@ -423,6 +430,11 @@ __device__ __forceinline__ void spectrum_form(const FrameArgs& a, F&& f)
     } else if (__builtin_expect(a.omega_q != nullptr, 1)) f(std::false_type{}, std::true_type{});
     else f(std::false_type{}, std::false_type{});
 }
+// tile sizes whose spectrum is read with non-temporal loads (the usual form: fp32 spectrum, 16-bit dispersion)
+#ifndef OCEAN_SPEC_NT_MIN
+#define OCEAN_SPEC_NT_MIN 4096
+#endif
+template <int N> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC_NT_MIN; }
 template <int N, bool H16, bool W16>
 __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
                                                 float4& ha, float2& hb0, float2& hb1, float2& w)
@@ -435,6 +447,19 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
     ha = make_float4(1.f + g, 2.f, 3.f, 4.f); hb0 = make_float2(0.5f, 1.5f); hb1 = make_float2(2.5f, 3.5f); w = make_float2(0.5f, 0.25f);
     return;
 #endif
+    if constexpr (spectrum_nt<N>() && !H16 && W16) {
+        // beyond the memory-side cache (4096^2: 151 MB of spectrum, read once per z pass): streamed past it, so that the intermediates
+        // -- written here, re-read by the x pass right behind -- are what stays resident (ocean_launch.h: the split frame order)
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        typedef float nt2 __attribute__((ext_vector_type(2)));
+        const float2* __restrict__ h0 = a.h0 + tile * n2;
+        const nt4 va = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(h0 + g));
+        const nt2 v0 = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(h0 + m0)), v1 = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(h0 + m1));
+        ha = make_float4(va.x, va.y, va.z, va.w); hb0 = make_float2(v0.x, v0.y); hb1 = make_float2(v1.x, v1.y);
+        const unsigned two = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g));
+        w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+        return;
+    }
     if constexpr (H16) {
         const __half2* __restrict__ hh = a.h0h + tile * n2;
         const float2 raw2 = *reinterpret_cast<const float2*>(hh + g);       // two half2
@@ -827,7 +852,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
         kx2 = c ? kx21 : kx20;
     };
     if (a.mode != 2) {
-        {   // pair 0: (uz Tz, -ux Tx)
+        if (a.zmask & 1) {   // pair 0: (uz Tz, -ux Tx)
             auto in = [&](int e, int c, int, int i) -> c32 {
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<0>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
@@ -835,7 +860,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
-        {   // pair 1: (-kz Tz, kx Tx)
+        if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
             auto in = [&](int e, int c, int, int i) -> c32 {
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<1>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
@@ -844,7 +869,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
     }
-    if (a.mode == 0 || a.mode == 3) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
+    if ((a.mode == 0 || a.mode == 3) && (a.zmask & 4)) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
         auto in = [&](int e, int c, int, int i) -> c32 {
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
             return zpass_input<2>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
@@ -852,7 +877,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
         auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
-    {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
+    if (a.zmask & 8) {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
         auto in = [&](int e, int c, int, int i) -> c32 {
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
             if (!jac) return make_float2(sv, 0.0f);
@@ -947,7 +972,7 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
             }
         }
     });
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tid == 0 && (a.zmask & 8)) {   // (the launch that transforms the height: ahead of the HEIGHT workgroups' atomics)
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
         a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
@@ -1045,8 +1070,9 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             tc = tz;
         }
     };
+    // (a.zmask: which of the four this launch runs -- all of them, or one half of the split frame order; wave-uniform)
     if (a.mode != 2) {
-        {   // pair 0: (uz Tz, -ux Tx)
+        if (a.zmask & 1) {   // pair 0: (uz Tz, -ux Tx)
             auto in = [&](int e, int, int, int i) -> c32 {
                 float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
@@ -1054,7 +1080,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb, p, u, i), v, su); };
             batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
-        {   // pair 1: (-kz Tz, kx Tx)
+        if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
             auto in = [&](int e, int, int, int i) -> c32 {
                 float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
@@ -1063,7 +1089,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
     }
-    if (a.mode == 0 || a.mode == 3) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
+    if ((a.mode == 0 || a.mode == 3) && (a.zmask & 4)) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
         auto in = [&](int e, int, int, int i) -> c32 {
             float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
@@ -1071,7 +1097,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
         auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
         batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
-    {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
+    if (a.zmask & 8) {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
         auto in = [&](int e, int, int, int i) -> c32 {
             float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
             if (!jac) return make_float2(sv, 0.0f);
@@ -1132,7 +1158,7 @@ __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs 
             }
         }
     });
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tid == 0 && (a.zmask & 8)) {   // (the launch that transforms the height: ahead of the HEIGHT workgroups' atomics)
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
         a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
@@ -1252,6 +1278,53 @@ template <int N, int C> constexpr bool xpass_single_row_group() { return C > 1 &
 // all-padding group behind them)
 template <int N, int C> constexpr int xpass_height_groups() { return (N / 2 + 1 + 2 * C - 1) / (2 * C); }
 
+// Completion record of a frame.  The workgroup of the frame's last launch (the displacement pass; the normal-map role in the split frame order) that finishes LAST hands, per tile, one 16-byte record
+// (min key, max key, frame sequence number, 0) to host-coherent memory: a synchronous ComputeWaves returns from a short poll of
+// those words instead of a stream synchronisation (ocean_compute_waves; 13-16 us of wake-up per call at the reference's call
+// shape, WaterSurfaceMesh.cpp:145-154).  A record is one store instruction of one lane -- the host never sees half of one -- and
+// carries its own sequence number, so nothing depends on the order in which records arrive.  It tells the host that the frame's
+// work is done; it is not a memory fence: whatever reads the maps is ordered by the stream, as before.
+// Counting is two-level -- workgroup -> one of up to DONE_GROUPS group counters (a cache line each) -> the top counter -- because
+// the workgroups of a round finish together and a single word takes ~88 atomics per microsecond (257 of them: +2 us on the 2048^2
+// displacement pass; two-level: see DESIGN.md section 6).
+constexpr unsigned DONE_GROUPS = 1024, DONE_STRIDE = 16;      // counter g at done_ctr[(1 + g) * DONE_STRIDE], the top one at [0]
+template <int T>
+__device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_flag, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's map stores have been taken
+    __syncthreads();                                        // ... every wave's; nobody reads the FFT image any more
+    if (tid == 0) {
+        const unsigned total = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned groups = total / 16u < DONE_GROUPS ? (total + 15u) / 16u : DONE_GROUPS;
+        const unsigned g = id % groups, members = total / groups + (g < total % groups ? 1u : 0u);
+        unsigned* gc = a.done_ctr + (1u + g) * DONE_STRIDE;
+        bool last = false;
+        if (atomicAdd(gc, 1u) == members - 1u) {             // last of its group: the group counter is free again, one add upstairs
+            *gc = 0u;
+            last = atomicAdd(a.done_ctr, 1u) == groups - 1u;
+        }
+        lds_flag[0] = last;
+    }
+    __syncthreads();
+    if (!lds_flag[0]) return;
+    if (tid == 0) *a.done_ctr = 0u;                         // for the chain's next frame (stream order)
+    for (unsigned i = (unsigned)tid; i < gridDim.y; i += (unsigned)T)
+        a.done_rec[i] = make_uint4(a.minmax[2 * i + 0], a.minmax[2 * i + 1], a.frame_seq, 0u);     // one 16-byte store
+}
+
+
+// The records of a launch (FrameArgs::rec_mode): the early form by the first workgroup of each tile (the height keys are final when the
+// frame's last launches run), or the counted form.  Called by every thread of every workgroup of the launch, behind its work.
+template <int T>
+__device__ __forceinline__ void frame_records(const FrameArgs& a, unsigned* lds_flag, int tid, bool first_of_tile)
+{
+    if (a.rec_mode == 1) {
+        if (first_of_tile && tid == 0) a.done_rec[blockIdx.y] = make_uint4(a.minmax[2 * blockIdx.y + 0], a.minmax[2 * blockIdx.y + 1], a.frame_seq, 0u);
+    } else if (a.rec_mode == 2) {
+        frame_done<T>(a, lds_flag, tid);
+    }
+}
+
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 {
@@ -1269,16 +1342,18 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     constexpr int NB = (HF::NU + C - 1) / C;              // normal workgroups
     constexpr int HB = JAC ? NB : xpass_height_groups<N, C>();      // height workgroups
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
+    // a launch holds the HEIGHT workgroups, the NORMAL workgroups or (usually) both: a.xb_roles; bx = the index in the full grid
+    const int bx = (int)blockIdx.x + (a.xb_roles == 2 ? HB : 0);
 
     if constexpr (JAC) {
         // ---- PAIR-3 workgroup (OCEAN_MODE_JACOBIAN): the height travels as the real part of pair 3 with the cross
         // derivative as its imaginary part, so C rows per workgroup like every pair (not 2 C real rows): raw signed
         // height and cross derivative of rows u0 .. u0+C-1 out (both even: the mirrored rows hold the same values),
         // global min/max of the height.
-        if (blockIdx.x < HB) {
+        if (bx < HB) {
             constexpr int NW = (T + 63) / 64;
             float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
-            const int u0 = xcd_swizzle(blockIdx.x, HB) * C;
+            const int u0 = xcd_swizzle(bx, HB) * C;
             const float2* __restrict__ z3 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z3) + (size_t)tile * HF::Z_GROUP * (Z16 ? 4 : 8));
             float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
             float* __restrict__ jraw = a.jraw + (size_t)tile * HF::HRAW_TILE;
@@ -1312,10 +1387,10 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             return;
         }
     }
-    if (!JAC && blockIdx.x < HB) {
+    if (!JAC && bx < HB) {
         constexpr int NW = (T + 63) / 64;
         float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
-        const int u0 = xcd_swizzle(blockIdx.x, HB) * 2 * C;
+        const int u0 = xcd_swizzle(bx, HB) * 2 * C;
         constexpr size_t ES = Z16 ? 4 : 8;
         const float2* __restrict__ zh = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zh) + (size_t)tile * HF::ZH_TILE * ES);
         float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
@@ -1384,7 +1459,10 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     // same box, interleaved) and costs nothing anywhere else.
     // (From 2048 up, where a tile's workgroups outnumber the CUs; at 512^2 and 1024^2 -- every workgroup alone on a CU -- the plain swizzle is
     // 0.3-0.5 us faster and stays.)
-    const int nid = (int)blockIdx.x - HB;
+    // (the role's body as a lambda: its reduced modes leave early, and in the split frame order -- where this is the frame's LAST launch --
+    //  every thread of the workgroup must still reach frame_records below)
+    auto normal_role = [&]() {
+    const int nid = bx - HB;
     const int u0 = (N >= 2048 ? (nid == 0 ? NB - 1 : xcd_swizzle(nid - 1, NB - 1)) : xcd_swizzle(nid, NB)) * C;
     start_ramp_wait(a.start_ramp, (unsigned)nid, (unsigned)NB);    // the NORMAL workgroups alone (one 2048^2 tile: ocean_launch.h)
     constexpr size_t ESN = Z16 ? 4 : 8;
@@ -1485,42 +1563,10 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         auto out = [&](int p, int c, c32 v, int u, int i) { emit(p, c, held[u][i], v); };
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
+    };
+    normal_role();
+    frame_records<T>(a, reinterpret_cast<unsigned*>(smem), tid, bx == HB);
 }
-
-// Completion record of a frame.  The workgroup of the displacement pass that finishes LAST hands, per tile, one 16-byte record
-// (min key, max key, frame sequence number, 0) to host-coherent memory: a synchronous ComputeWaves returns from a short poll of
-// those words instead of a stream synchronisation (ocean_compute_waves; 13-16 us of wake-up per call at the reference's call
-// shape, WaterSurfaceMesh.cpp:145-154).  A record is one store instruction of one lane -- the host never sees half of one -- and
-// carries its own sequence number, so nothing depends on the order in which records arrive.  It tells the host that the frame's
-// work is done; it is not a memory fence: whatever reads the maps is ordered by the stream, as before.
-// Counting is two-level -- workgroup -> one of up to DONE_GROUPS group counters (a cache line each) -> the top counter -- because
-// the workgroups of a round finish together and a single word takes ~88 atomics per microsecond (257 of them: +2 us on the 2048^2
-// displacement pass; two-level: see DESIGN.md section 6).
-constexpr unsigned DONE_GROUPS = 1024, DONE_STRIDE = 16;      // counter g at done_ctr[(1 + g) * DONE_STRIDE], the top one at [0]
-template <int T>
-__device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_flag, int tid)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's map stores have been taken
-    __syncthreads();                                        // ... every wave's; nobody reads the FFT image any more
-    if (tid == 0) {
-        const unsigned total = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned groups = total / 16u < DONE_GROUPS ? (total + 15u) / 16u : DONE_GROUPS;
-        const unsigned g = id % groups, members = total / groups + (g < total % groups ? 1u : 0u);
-        unsigned* gc = a.done_ctr + (1u + g) * DONE_STRIDE;
-        bool last = false;
-        if (atomicAdd(gc, 1u) == members - 1u) {             // last of its group: the group counter is free again, one add upstairs
-            *gc = 0u;
-            last = atomicAdd(a.done_ctr, 1u) == groups - 1u;
-        }
-        lds_flag[0] = last;
-    }
-    __syncthreads();
-    if (!lds_flag[0]) return;
-    if (tid == 0) *a.done_ctr = 0u;                         // for the chain's next frame (stream order)
-    for (unsigned i = (unsigned)tid; i < gridDim.y; i += (unsigned)T)
-        a.done_rec[i] = make_uint4(a.minmax[2 * i + 0], a.minmax[2 * i + 1], a.frame_seq, 0u);     // one 16-byte store
-}
-
 
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
 __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const FrameArgs a)
@@ -1566,7 +1612,7 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
             }
         }
         const unsigned kmn = a.minmax[2 * tile + 0], kmx = a.minmax[2 * tile + 1];      // final by now
-        if (!a.done_ctr && blockIdx.x == 0 && tid == 0) a.done_rec[tile] = make_uint4(kmn, kmx, a.frame_seq, 0u);
+        if (a.rec_mode == 1 && blockIdx.x == 0 && tid == 0) a.done_rec[tile] = make_uint4(kmn, kmx, a.frame_seq, 0u);
         const float mn = key_float(kmn);
         const float mx = key_float(kmx);
         const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
@@ -1598,7 +1644,7 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
     } else {
         rows(std::integral_constant<int, C>{});
     }
-    if (a.done_ctr) frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
+    if (a.rec_mode == 2) frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
 }
 
 #ifdef OCEAN_INIT_KERNELS

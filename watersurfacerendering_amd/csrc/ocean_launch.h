@@ -25,9 +25,17 @@ static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
     else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
+// Where the split frame order (launch_frame: by output map, the spectrum animated twice) is the faster one when the context leaves the
+// choice to the library (ocean_set_frame_order(ctx, 0)).
+template <int N> inline bool split_order_pays(int stream_maps, unsigned tiles)
+{
+    (void)stream_maps; (void)tiles;
+    return false;
+}
+
 template <int N>
 static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
-                               hipStream_t st, hipEvent_t* marks /* 6 events (start, stop per kernel) or null */)
+                               hipStream_t st, hipEvent_t* marks /* 2 x OCEAN_MAX_LAUNCHES events (start, stop per launch) or null */)
 {
     using G = Geo<N>;
     using HF = Half<N>;
@@ -110,20 +118,38 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     };
     arm(0);
 #endif
-    {
-        // the form of the z pass (see above); the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the
-        // other forms' code (FAST)
-        bool c1 = HASC1 && zpass_c1_pays<N>(stream_maps, tiles);
-        bool zw2 = HAS2 && !c1 && (stream_maps & 4);
+    // the form of the z pass (see above); the usual form of the spectrum (fp32 h0, 16-bit dispersion) has instantiations without the
+    // other forms' code (FAST)
+    bool c1 = HASC1 && zpass_c1_pays<N>(stream_maps, tiles);
+    bool zw2 = HAS2 && !c1 && (stream_maps & 4);
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
-        static const char* const c1_env = getenv("OCEAN_ZC1");                  // 0 / 1
-        if (c1_env && HASC1) c1 = atoi(c1_env) != 0;
-        zw2 = HAS2 && !c1 && (stream_maps & 4);
-        static const char* const zw_env = getenv("OCEAN_ZW");                   // 1 or 2
-        if (zw_env && HAS2 && !c1) zw2 = atoi(zw_env) == 2;
+    static const char* const c1_env = getenv("OCEAN_ZC1");                  // 0 / 1
+    if (c1_env && HASC1) c1 = atoi(c1_env) != 0;
+    zw2 = HAS2 && !c1 && (stream_maps & 4);
+    static const char* const zw_env = getenv("OCEAN_ZW");                   // 1 or 2
+    if (zw_env && HAS2 && !c1) zw2 = atoi(zw_env) == 2;
 #endif
+    // Frame order.  Standard: z pass (four transforms per column) -> k_xpass_b (HEIGHT + NORMAL workgroups) -> k_xpass_disp.  SPLIT, by output
+    // map: z pass {height, pair 0} -> HEIGHT workgroups -> k_xpass_disp, then z pass {pair 1, pair 2} -> NORMAL workgroups: each half keeps
+    // 6 / 8 instead of 14 B/texel of intermediates alive between its two passes -- at 4096^2 101 / 134 MB, which the 256 MiB memory-side cache
+    // holds where it does not hold the 235 MB of the standard order (their round trip is then HBM traffic) -- and pays for it by animating
+    // the spectrum twice (+9 B/texel of reads).  The z-pass forms with one transform per batch can run any subset of a column's transforms
+    // (FrameArgs::zmask); the Jacobian mode cannot split (its displacement pass needs the normal-map role's product plane) and the
+    // height-only mode has nothing to split.  Same instantiations, same inputs, same bits (tests/test_variants_gpu.py).
+    const bool split = (c1 || zw2) && (a.mode == 0 || a.mode == 1) &&
+                       (c->frame_order == 2 || (c->frame_order == 0 && split_order_pays<N>(stream_maps, tiles)));
+    int launches = 0;
+    auto next_marks = [&](int kernel) -> hipEvent_t* {      // the event pair of the frame's next launch; remembers which kernel it times
+        c->launch_kernel[launches] = kernel;
+        hipEvent_t* m = marks ? marks + 2 * launches : nullptr;
+        ++launches;
+        return m;
+    };
+    const int rec_last = a.rec_mode;                         // what the frame's LAST launch does with the completion records (ocean_api.hip)
+    auto launch_z = [&](int zmask) -> hipError_t {
         unsigned gx = zw2 ? N / 4 + 1 : N / 2 + 1;
         FrameArgs za = a;
+        za.zmask = zmask; za.rec_mode = 0;
         // one 2048^2 tile: the single-transform form's 1025 workgroups are one resident round -- staggered start (start_ramp_wait)
         za.start_ramp = c1 ? ramp_z : 0;
 #if defined(OCEAN_STAMPS) || defined(OCEAN_DEVELOPER)
@@ -132,7 +158,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         const unsigned threads = c1 ? (unsigned)zpass_c1_threads<N>() : (unsigned)G::T_ROWS;
         const size_t lds = c1 ? zpass_c1_lds_bytes<N>() : (zw2 ? lds_rows2 : lds_rows);
         const dim3 grid(gx, tiles), block(threads);
-        {
+        if (launches == 0) {
             ocean_launch_info& li = c->last_launch[0];
             li.tile_size = N; li.grid_x = gx; li.grid_y = tiles; li.block = threads; li.mode = (uint32_t)a.mode;
             li.per_workgroup = zw2 ? 2u : 1u;
@@ -140,13 +166,14 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.flags = ((stream_maps & 4) ? OCEAN_LAUNCH_NT_INTER : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
                        (a.mode == 3 ? OCEAN_LAUNCH_JACOBIAN : 0u) | (a.h0h ? OCEAN_LAUNCH_FP16_SPECTRUM : 0u) |
                        (a.omega_q ? 0u : OCEAN_LAUNCH_FP32_DISPERSION) | (c1 ? OCEAN_LAUNCH_SINGLE_TRANSFORM : 0u) |
-                       (za.start_ramp ? OCEAN_LAUNCH_STAGGERED_START : 0u);
+                       (za.start_ramp ? OCEAN_LAUNCH_STAGGERED_START : 0u) | (split ? OCEAN_LAUNCH_SPLIT_ORDER : 0u);
         }
+        hipEvent_t* mz = next_marks(0);
         bool launched = false;
 #define OCEAN_ZPASS3(znt, z16, fast) \
-        do { if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, grid, block, lds, st, marks, za); launched = true; break; } } \
-             if constexpr (HAS2 && (znt || HAS2_PLAIN)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds, st, marks, za); launched = true; break; } } \
-             if constexpr (HAS1) { if (!c1 && !zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds, st, marks, za); launched = true; } } } while (0)
+        do { if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
+             if constexpr (HAS2 && (znt || HAS2_PLAIN)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
+             if constexpr (HAS1) { if (!c1 && !zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds, st, mz, za); launched = true; } } } while (0)
 #define OCEAN_ZPASS2(znt, z16) \
         do { if (fast) OCEAN_ZPASS3(znt, z16, true); else OCEAN_ZPASS3(znt, z16, false); } while (0)
 #define OCEAN_ZPASS(znt) \
@@ -156,35 +183,31 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #undef OCEAN_ZPASS2
 #undef OCEAN_ZPASS3
         if (!launched) return hipErrorInvalidConfiguration;     // (a form this build does not carry: the rules above never ask for one)
-        if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;   // the first frames after a drain: the next chain's z pass starts behind this one (ocean_api.hip)
-    }
-#ifdef OCEAN_STAMPS
-    if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
-    arm(1);
-#endif
-    {
-        const bool jac = a.mode == 3;       // OCEAN_MODE_JACOBIAN: the height role works on pair 3, C rows per workgroup
-        dim3 gb((jac ? nb : hb_b) + nb, tiles), gd(nb, tiles), blk(G::T_C);
-#ifdef OCEAN_XBGRID
-        if (const char* ev = getenv("OCEAN_DEBUG_XB_GRID")) gb.x = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
-        if (const char* ev = getenv("OCEAN_DEBUG_XD_GRID")) gd.x = (unsigned)atoi(ev);
-#endif
-        hipEvent_t* mb = marks ? marks + 2 : nullptr;
-        hipEvent_t* md = marks ? marks + 4 : nullptr;
-        for (int k = 1; k <= 2; ++k) {
-            ocean_launch_info& li = c->last_launch[k];
-            li.tile_size = N; li.grid_x = k == 1 ? gb.x : gd.x; li.grid_y = tiles; li.block = G::T_C; li.mode = (uint32_t)a.mode;
-            li.per_workgroup = C;
-            li.lds_bytes = (uint32_t)(k == 1 ? lds_b : lds_m);
-            li.flags = ((stream_maps & (k == 1 ? 1 : 2)) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
-                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | ((k == 1 ? ramp_b : ramp_d) ? OCEAN_LAUNCH_STAGGERED_START : 0u);
-        }
+        return hipSuccess;
+    };
+    const bool jac = a.mode == 3;       // OCEAN_MODE_JACOBIAN: the height role works on pair 3, C rows per workgroup
+    const unsigned hb = jac ? nb : hb_b;
+    const dim3 blk(G::T_C);
 #define OCEAN_XPASS2(kern, grid, lds, ev, nts, z16, args)                                                          \
         do { if (jac) launch(kern<N, C, G::T_C, typename G::PC, nts, z16, true>, grid, blk, lds, st, ev, args);       \
              else launch(kern<N, C, G::T_C, typename G::PC, nts, z16, false>, grid, blk, lds, st, ev, args); } while (0)
 #define OCEAN_XPASS(kern, grid, lds, ev, nts, args)                                                                 \
         do { if (stream_maps & 8) OCEAN_XPASS2(kern, grid, lds, ev, nts, true, args);                                 \
              else OCEAN_XPASS2(kern, grid, lds, ev, nts, false, args); } while (0)
+    auto launch_xb = [&](int roles, int rec_mode) {
+        dim3 gb((roles & 1 ? hb : 0u) + (roles & 2 ? nb : 0u), tiles);
+#ifdef OCEAN_XBGRID
+        if (const char* ev = getenv("OCEAN_DEBUG_XB_GRID")) gb.x = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
+#endif
+        if (roles & 2) {
+            ocean_launch_info& li = c->last_launch[1];
+            li.tile_size = N; li.grid_x = gb.x; li.grid_y = tiles; li.block = G::T_C; li.mode = (uint32_t)a.mode;
+            li.per_workgroup = C;
+            li.lds_bytes = (uint32_t)lds_b;
+            li.flags = ((stream_maps & 1) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | (ramp_b ? OCEAN_LAUNCH_STAGGERED_START : 0u) | (split ? OCEAN_LAUNCH_SPLIT_ORDER : 0u);
+        }
+        hipEvent_t* mb = next_marks(1);
 #ifdef OCEAN_XB_TRACE
         {   // diagnostic: this translation unit's copy of the trace pointer, set when the context's buffer changes (not per frame)
             static unsigned long long* armed = nullptr;
@@ -192,19 +215,54 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         }
 #endif
         FrameArgs ba = a;
+        ba.xb_roles = roles; ba.rec_mode = rec_mode;
         ba.start_ramp = ramp_b;             // over its normal-map workgroups (the height workgroups start at once)
         if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true, ba);
         else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false, ba);
-#ifdef OCEAN_STAMPS
-        arm(2);
+    };
+    auto launch_xd = [&](int rec_mode) {
+        dim3 gd(nb, tiles);
+#ifdef OCEAN_XBGRID
+        if (const char* ev = getenv("OCEAN_DEBUG_XD_GRID")) gd.x = (unsigned)atoi(ev);
 #endif
+        {
+            ocean_launch_info& li = c->last_launch[2];
+            li.tile_size = N; li.grid_x = gd.x; li.grid_y = tiles; li.block = G::T_C; li.mode = (uint32_t)a.mode;
+            li.per_workgroup = C;
+            li.lds_bytes = (uint32_t)lds_m;
+            li.flags = ((stream_maps & 2) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | (ramp_d ? OCEAN_LAUNCH_STAGGERED_START : 0u) | (split ? OCEAN_LAUNCH_SPLIT_ORDER : 0u);
+        }
+        hipEvent_t* md = next_marks(2);
         FrameArgs da = a;
+        da.rec_mode = rec_mode;
         da.start_ramp = ramp_d;             // its 257 workgroups are one per CU: the same read-then-write burst
         if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true, da);
         else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false, da);
+    };
+    if (!split) {
+        if ((e = launch_z(15)) != hipSuccess) return e;
+        if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;   // the first frames after a drain: the next chain's z pass starts behind this one (ocean_api.hip)
+#ifdef OCEAN_STAMPS
+        if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
+        arm(1);
+#endif
+        launch_xb(3, 0);
+#ifdef OCEAN_STAMPS
+        arm(2);
+#endif
+        launch_xd(rec_last);
+    } else {
+        if ((e = launch_z(8 | 1)) != hipSuccess) return e;
+        if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;
+        launch_xb(1, 0);
+        launch_xd(rec_last == 1 ? 1 : 0);                   // (early records may go out here: the height keys are final; counted ones come from the last launch)
+        if ((e = launch_z(2 | 4)) != hipSuccess) return e;
+        launch_xb(2, rec_last == 2 ? 2 : 0);
+    }
 #undef OCEAN_XPASS2
 #undef OCEAN_XPASS
-    }
+    c->launch_count = launches;
     return hipGetLastError();
 }
 
