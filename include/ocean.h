@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 4   /* 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp, ocean_set_frame_order (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
+#define OCEAN_ABI_VERSION 4   /* 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
                                  ocean_set_frame_tracking, ocean_last_launch, ocean_export_maps, ocean_bind_output_dmabuf, ocean_select_streams,
                                  ocean_comm_count, ocean_algorithmic_bytes_per_launch (additions only) */
 
@@ -382,14 +382,6 @@ int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [
  * THIS device (grid <= compute units x workgroups per unit); on != 0 (default) allows it, 0 switches it off for the context -- for a device
  * shared with other work, where a workgroup's wait is simply lost.  Frames are bit-identical either way.                                    */
 int ocean_set_start_ramp(ocean_t* ctx, int on);
-/* Order of a frame's launches.  OCEAN_ORDER_STANDARD: z pass (all four transforms of a spectrum column) -> height + normal-map
- * workgroups -> displacement pass: three launches.  OCEAN_ORDER_SPLIT: by output map -- z pass {height, pair 0} -> height workgroups ->
- * displacement pass -> z pass {pair 1, pair 2} -> normal-map workgroups: five launches; each half keeps under half of the intermediates
- * alive between its passes (what a tile beyond the memory-side cache gains) and animates the spectrum for itself (what it costs).  Tile
- * sizes from 1024 up, FULL7 and CHOPPY5 modes; asked for anything else the library runs the standard order (ocean_last_launch says which:
- * OCEAN_LAUNCH_SPLIT_ORDER).  OCEAN_ORDER_AUTO (default): the library chooses per frame.  Frames are bit-identical in either order.      */
-enum { OCEAN_ORDER_AUTO = 0, OCEAN_ORDER_STANDARD = 1, OCEAN_ORDER_SPLIT = 2 };
-int ocean_set_frame_order(ocean_t* ctx, int order);
 
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */
@@ -432,9 +424,8 @@ enum {
                                             at once, start spread over a few microseconds so that the early ones store while
                                             the late ones still load -- the three launches of a frame of one 2048^2 tile
                                             (serial and pipelined frames with ramps of their own), nowhere else          */
-    OCEAN_LAUNCH_SPLIT_ORDER     = 512   /* not a variant either: the frame ran in the split order (ocean_set_frame_order) -- its z pass
-                                            and k_xpass_b twice, each time for half of their work; idx 0 describes the first z-pass
-                                            launch, idx 1 the normal-map launch of k_xpass_b                               */
+    OCEAN_LAUNCH_SPLIT_ORDER     = 512   /* developer builds only (never set by the shipped library): the frame ran in the split order of
+                                            profiles/r05_4096_experiments.txt -- z pass and k_xpass_b twice, each time half their work        */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

@@ -263,10 +263,6 @@ class OceanBatch:
     def set_pipeline_depth(self, depth: int):
         _abi.check(self._L.ocean_set_pipeline_depth(self._h, depth), "ocean_set_pipeline_depth")
 
-    def set_frame_order(self, order: int):
-        """0 the library chooses, 1 standard (three launches), 2 split by output map (five launches): include/ocean.h."""
-        _abi.check(self._L.ocean_set_frame_order(self._h, order), "ocean_set_frame_order")
-
     def set_start_ramp(self, on: bool):
         _abi.check(self._L.ocean_set_start_ramp(self._h, int(bool(on))), "ocean_set_start_ramp")
 

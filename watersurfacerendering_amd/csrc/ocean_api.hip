@@ -1108,13 +1108,6 @@ int ocean_set_pipeline_depth(ocean_t* c, int depth)
     return OCEAN_OK;
 }
 
-int ocean_set_frame_order(ocean_t* c, int order)
-{
-    if (!c || order < OCEAN_ORDER_AUTO || order > OCEAN_ORDER_SPLIT) return OCEAN_E_INVALID;
-    c->frame_order = order;             // takes effect at the next frame
-    return OCEAN_OK;
-}
-
 int ocean_set_start_ramp(ocean_t* c, int on)
 {
     if (!c) return OCEAN_E_INVALID;

@@ -11,7 +11,7 @@
 #include "ocean_kernels.h"
 
 constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
-constexpr int OCEAN_MAX_LAUNCHES = 5;   // launches per frame: three, or five in the split frame order (ocean_launch.h)
+constexpr int OCEAN_MAX_LAUNCHES = 5;   // launches per frame: three (five in the developer-only split order: ocean_launch.h)
 
 struct ocean_ctx {
     uint32_t n = 0;
@@ -97,9 +97,8 @@ struct ocean_ctx {
     hipEvent_t start_ev = nullptr;      // ocean_time_frames: start of the timed region
     hipEvent_t end_ev[MAXD] = {};       //                    end of every chain
     hipEvent_t mark_ev[MAXD][2 * OCEAN_MAX_LAUNCHES] = {};   // per-launch timing: (start, stop) of each launch of a frame
-    int launch_count = 3;               // launches of the most recent frame (3; 5 in the split order) and the kernel (0 z pass, 1 k_xpass_b,
+    int launch_count = 3;               // launches of the most recent frame (3; 5 in the developer-only split order) and the kernel (0 z pass, 1 k_xpass_b,
     int launch_kernel[OCEAN_MAX_LAUNCHES] = {0, 1, 2, 0, 1};   //   2 k_xpass_disp) each of them ran: ocean_time_frames sums a kernel's launches
-    int frame_order = 0;                // ocean_set_frame_order: 0 the library chooses, 1 standard, 2 split by output map (ocean_launch.h)
     ocean_launch_info last_launch[3] = {};  // what the most recent frame launched (ocean_last_launch)
     hipEvent_t z_done[MAXD] = {};       // pipelined frames right after a drain: recorded behind a chain's z pass (see enqueue_frame)
     hipEvent_t after_z = nullptr;       // what launch_frame records behind the z pass of the frame being enqueued (null: nothing)

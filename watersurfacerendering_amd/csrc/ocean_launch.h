@@ -25,14 +25,6 @@ static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
     else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
-// Where the split frame order (launch_frame: by output map, the spectrum animated twice) is the faster one when the context leaves the
-// choice to the library (ocean_set_frame_order(ctx, 0)).
-template <int N> inline bool split_order_pays(int stream_maps, unsigned tiles)
-{
-    (void)stream_maps; (void)tiles;
-    return false;
-}
-
 template <int N>
 static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
                                hipStream_t st, hipEvent_t* marks /* 2 x OCEAN_MAX_LAUNCHES events (start, stop per launch) or null */)
@@ -129,15 +121,16 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     static const char* const zw_env = getenv("OCEAN_ZW");                   // 1 or 2
     if (zw_env && HAS2 && !c1) zw2 = atoi(zw_env) == 2;
 #endif
-    // Frame order.  Standard: z pass (four transforms per column) -> k_xpass_b (HEIGHT + NORMAL workgroups) -> k_xpass_disp.  SPLIT, by output
-    // map: z pass {height, pair 0} -> HEIGHT workgroups -> k_xpass_disp, then z pass {pair 1, pair 2} -> NORMAL workgroups: each half keeps
-    // 6 / 8 instead of 14 B/texel of intermediates alive between its two passes -- at 4096^2 101 / 134 MB, which the 256 MiB memory-side cache
-    // holds where it does not hold the 235 MB of the standard order (their round trip is then HBM traffic) -- and pays for it by animating
-    // the spectrum twice (+9 B/texel of reads).  The z-pass forms with one transform per batch can run any subset of a column's transforms
-    // (FrameArgs::zmask); the Jacobian mode cannot split (its displacement pass needs the normal-map role's product plane) and the
-    // height-only mode has nothing to split.  Same instantiations, same inputs, same bits (tests/test_variants_gpu.py).
-    const bool split = (c1 || zw2) && (a.mode == 0 || a.mode == 1) &&
-                       (c->frame_order == 2 || (c->frame_order == 0 && split_order_pays<N>(stream_maps, tiles)));
+    // Frame order: z pass (four transforms per column) -> k_xpass_b (HEIGHT + NORMAL workgroups) -> k_xpass_disp.  Developer builds can run
+    // the SPLIT order of profiles/r05_4096_experiments.txt instead (OCEAN_FRAME_ORDER=2: z pass {height, pair 0} -> HEIGHT workgroups ->
+    // k_xpass_disp -> z pass {pair 1, pair 2} -> NORMAL workgroups; bit-identical, slower at every size -- the x passes sit on the map write
+    // stream, not on their reads, and the second animation of the spectrum is paid in full); the per-launch fields it needs (zmask, xb_roles,
+    // rec_mode) are part of every launch.
+    bool split = false;
+#ifdef OCEAN_DEVELOPER
+    {   const char* const fo = getenv("OCEAN_FRAME_ORDER");       // (read per frame: tools/ab_order.py flips it between passes)
+        split = fo && atoi(fo) == 2 && (c1 || zw2) && (a.mode == 0 || a.mode == 1); }
+#endif
     int launches = 0;
     auto next_marks = [&](int kernel) -> hipEvent_t* {      // the event pair of the frame's next launch; remembers which kernel it times
         c->launch_kernel[launches] = kernel;
