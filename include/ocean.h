@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 4   /* 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
+#define OCEAN_ABI_VERSION 4   /* 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp, ocean_set_merged_xpass (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
                                  ocean_set_frame_tracking, ocean_last_launch, ocean_export_maps, ocean_bind_output_dmabuf, ocean_select_streams,
                                  ocean_comm_count, ocean_algorithmic_bytes_per_launch (additions only) */
 
@@ -382,6 +382,12 @@ int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [
  * THIS device (grid <= compute units x workgroups per unit); on != 0 (default) allows it, 0 switches it off for the context -- for a device
  * shared with other work, where a workgroup's wait is simply lost.  Frames are bit-identical either way.                                    */
 int ocean_set_start_ramp(ocean_t* ctx, int on);
+/* The x axis in ONE launch (round 5): frames of a single small tile (N <= 512) run their height, normal-map and displacement workgroups
+ * as one grid -- the displacement workgroups transform at once and wait for the tile's height workgroups only before their stores -- two
+ * launches per frame instead of three (512^2: see DESIGN.md).  Applied only where every workgroup of that grid is resident at once, one per
+ * compute unit; never in OCEAN_MODE_JACOBIAN.  on != 0 (default) allows it, 0 keeps the three-launch frame.  Bit-identical either way;
+ * ocean_last_launch marks such a frame with OCEAN_LAUNCH_MERGED_X on idx 1 and 2 (the same launch).                                      */
+int ocean_set_merged_xpass(ocean_t* ctx, int on);
 
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */
@@ -424,8 +430,10 @@ enum {
                                             at once, start spread over a few microseconds so that the early ones store while
                                             the late ones still load -- the three launches of a frame of one 2048^2 tile
                                             (serial and pipelined frames with ramps of their own), nowhere else          */
-    OCEAN_LAUNCH_SPLIT_ORDER     = 512   /* developer builds only (never set by the shipped library): the frame ran in the split order of
+    OCEAN_LAUNCH_SPLIT_ORDER     = 512,  /* developer builds only (never set by the shipped library): the frame ran in the split order of
                                             profiles/r05_4096_experiments.txt -- z pass and k_xpass_b twice, each time half their work        */
+    OCEAN_LAUNCH_MERGED_X        = 1024  /* not a kernel variant: k_xpass_b ran the displacement workgroups as well (one launch for the whole x axis,
+                                            no k_xpass_disp); set on idx 1 and idx 2, which then describe that one launch                   */
 };
 typedef struct ocean_launch_info {
     uint32_t tile_size;

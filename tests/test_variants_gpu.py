@@ -168,10 +168,15 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
             assert z["tile_size"] == n and z["grid_y"] == tiles and z["mode"] == (3 if jac else 0), what
             split_seen |= bool(z["flags"] & A.OCEAN_LAUNCH_SPLIT_LAST_ROUND)
             stag = A.OCEAN_LAUNCH_STAGGERED_START                  # not a variant: the same instantiation, started differently
+            # nor is the merged x pass (round 5): k_xpass_b's instantiation with its DISP workgroups in the same launch -- single small tiles, not the Jacobian mode
+            merged = A.OCEAN_LAUNCH_MERGED_X
+            assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= 512 and tiles == 1 and not jac), what
+            if xb["flags"] & merged:
+                assert xb["grid_x"] == xd["grid_x"] and (xb["flags"] & ~A.OCEAN_LAUNCH_NT_MAPS) == (xd["flags"] & ~A.OCEAN_LAUNCH_NT_MAPS), what
             assert not any(li["flags"] & A.OCEAN_LAUNCH_SPLIT_ORDER for li in (z, xb, xd)), what      # (developer builds only: profiles/r05_4096_experiments.txt)
             for li in (z, xb, xd):
                 assert bool(li["flags"] & A.OCEAN_LAUNCH_STAGGERED_START) == (n == 2048 and tiles == 1 and (li is not z or bool(z["flags"] & A.OCEAN_LAUNCH_SINGLE_TRANSFORM))), what
-            seen.add((n, z["flags"] & ~(A.OCEAN_LAUNCH_SPLIT_LAST_ROUND | stag), z["per_workgroup"], xb["flags"] & ~stag, xd["flags"] & ~stag))
+            seen.add((n, z["flags"] & ~(A.OCEAN_LAUNCH_SPLIT_LAST_ROUND | stag), z["per_workgroup"], xb["flags"] & ~(stag | merged), xd["flags"] & ~(stag | merged)))
             # the store policies (and with them the one- and two-column z pass, the split last round) never change a bit
             if same is None:
                 same = (d, q, h)
@@ -255,3 +260,80 @@ def test_jacobian_buffers_are_allocated_by_the_first_frame_of_that_mode():
     assert torch.cuda.mem_get_info(0)[0] == free2
     b.close()
 
+
+
+@pytest.mark.parametrize("n", [16, 64, 256, 512])
+def test_merged_x_pass_delivers_the_bits_of_the_three_launch_frame(n, oracles):
+    """Round 5: frames of ONE small tile run the whole x axis as one launch -- k_xpass_b with its DISP workgroups, which
+    transform pair 0 at once and wait for the tile's HEIGHT workgroups (raw heights handed over write-through inside the launch) only before
+    their stores -- two launches per frame instead of three.  Against the three-launch frame (ocean_set_merged_xpass(ctx, 0)), bit for bit:
+    every mode that can merge x fp32 / half2 intermediates x synchronous calls (tracked: the merged launch's last workgroup writes the
+    records) / asynchronous frames at depth 1 and 4 (other chains' workgroups on the same compute units); the Jacobian mode and batches keep
+    three launches; and the first configuration meets the oracle directly."""
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi as A
+
+    def frames(merged, mode, bits, depth, sync, tiles=1):
+        b = W.OceanBatch(n, tiles, 0)
+        b.set_intermediate_precision(bits); b.set_mode(mode); b.set_pipeline_depth(depth); b.set_merged_xpass(merged)
+        b.prepare(SEED)
+        amps = None
+        if sync:
+            for t in (0.4, 0.9, T_FRAME):
+                amps = b.compute_waves(t)
+        else:
+            for j in range(2 * depth + 1):
+                b.compute_waves_async(T_FRAME if j == 2 * depth else 0.3 * j)
+            b.synchronize()
+        launches = b.last_launch()
+        d, q = b.read_maps()
+        h = [b.heights(i) for i in range(tiles)]
+        b.close()
+        return d, q, h, amps, launches
+
+    first = True
+    for mode, bits, (depth, sync) in itertools.product((A.OCEAN_MODE_FULL7, A.OCEAN_MODE_CHOPPY5, A.OCEAN_MODE_HEIGHT1), (32, 16), ((1, True), (1, False), (4, False))):
+        what = (n, mode, bits, depth, sync)
+        d1, q1, h1, a1, l1 = frames(False, mode, bits, depth, sync)
+        d2, q2, h2, a2, l2 = frames(True, mode, bits, depth, sync)
+        assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l1), what
+        assert l2[1]["flags"] & A.OCEAN_LAUNCH_MERGED_X and l2[2]["flags"] & A.OCEAN_LAUNCH_MERGED_X and l2[1]["grid_x"] > l1[1]["grid_x"], what
+        assert np.array_equal(d1, d2) and np.array_equal(q1, q2) and h1 == h2, what
+        if sync:
+            assert np.array_equal(a1, a2) and h2[0][0] == float(a2[0]), what
+        if first:
+            check_against_oracle(d2[0], q2[0], h2[0], oracles.frame(n, 200.0, False), False, TOL, what)
+            first = False
+    # where it does not apply the frame keeps three launches (and says so): the Jacobian mode, a batch
+    for mode, tiles in ((A.OCEAN_MODE_JACOBIAN, 1), (A.OCEAN_MODE_FULL7, 3)):
+        _, _, _, _, l = frames(True, mode, 32, 1, True, tiles)
+        assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l), (n, mode, tiles)
+    oracles.drop(n)
+
+
+def test_merged_x_pass_under_load_over_many_frames():
+    """The hand-off inside the merged launch (write-through stores, one counted arrival per HEIGHT workgroup, a polled wait) under the
+    conditions that expose a stale read: thousands of frames back to back at depth 4 -- other chains' workgroups on the same compute units,
+    warm L1s -- every frame's amplitude and a checksum of both maps against the three-launch context fed the same times."""
+    import watersurfacerendering_amd as W
+    n, frames = 512, 1500
+    ctx = []
+    for merged in (False, True):
+        b = W.OceanBatch(n, 1, 0)
+        b.set_pipeline_depth(4); b.set_merged_xpass(merged); b.set_frame_tracking(True)
+        b.prepare(SEED + 9)
+        ctx.append(b)
+    rng = np.random.default_rng(5)
+    times = rng.uniform(0.0, 500.0, size=frames).astype(np.float32)
+    for start in range(0, frames, 10):                 # ten frames in flight over four chains, then the last one's maps and heights
+        out = []
+        for b in ctx:
+            for t in times[start:start + 10]:
+                b.compute_waves_async(float(t))
+            amp = b.wait_frame()[0]                    # (tracked: the merged launch's last workgroup wrote the record)
+            d, q = b.read_maps()
+            out.append((float(amp), b.heights(0), d.copy(), q.copy()))
+        assert out[0][0] == out[1][0] and out[0][1] == out[1][1], start
+        assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3]), start
+    for b in ctx:
+        b.close()

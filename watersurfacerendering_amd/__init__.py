@@ -263,6 +263,9 @@ class OceanBatch:
     def set_pipeline_depth(self, depth: int):
         _abi.check(self._L.ocean_set_pipeline_depth(self._h, depth), "ocean_set_pipeline_depth")
 
+    def set_merged_xpass(self, on: bool):
+        _abi.check(self._L.ocean_set_merged_xpass(self._h, int(bool(on))), "ocean_set_merged_xpass")
+
     def set_start_ramp(self, on: bool):
         _abi.check(self._L.ocean_set_start_ramp(self._h, int(bool(on))), "ocean_set_start_ramp")
 

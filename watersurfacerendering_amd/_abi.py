@@ -39,13 +39,14 @@ SYMBOLS = [
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
     "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
     "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
-    "ocean_select_streams", "ocean_set_start_ramp", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
+    "ocean_select_streams", "ocean_set_start_ramp", "ocean_set_merged_xpass", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
 ]
 
 OCEAN_LAUNCH_NT_MAPS, OCEAN_LAUNCH_NT_INTER, OCEAN_LAUNCH_HALF_INTER, OCEAN_LAUNCH_JACOBIAN = 1, 2, 4, 8
 OCEAN_LAUNCH_FP16_SPECTRUM, OCEAN_LAUNCH_FP32_DISPERSION, OCEAN_LAUNCH_SPLIT_LAST_ROUND, OCEAN_LAUNCH_SINGLE_TRANSFORM = 16, 32, 64, 128
 OCEAN_LAUNCH_STAGGERED_START = 256
 OCEAN_LAUNCH_SPLIT_ORDER = 512      # developer builds only
+OCEAN_LAUNCH_MERGED_X = 1024
 
 
 class OceanError(RuntimeError):
@@ -205,6 +206,7 @@ def lib() -> C.CDLL:
         "ocean_read_xi": (i32, [P, u32, C.c_void_p]),
         "ocean_select_streams": (i32, [P, u32, FP]),
         "ocean_set_start_ramp": (i32, [P, i32]),
+        "ocean_set_merged_xpass": (i32, [P, i32]),
         "ocean_time_frames": (i32, [P, f32, f32, i32, i32, FP, FP]),
         "ocean_kernel_name": (C.c_char_p, [P, i32]),
         "ocean_last_launch": (i32, [P, i32, C.POINTER(LaunchInfo)]),

@@ -32,6 +32,7 @@ struct ocean_ctx {
     int last_set = 0;
     int cu_count = 0;               // compute units of the device
     bool start_ramp = true;         // ocean_set_start_ramp: the staggered start may be used where it applies (ocean_launch.h)
+    bool merged_x = true;           // ocean_set_merged_xpass: the one-launch x pass may be used where it applies (ocean_launch.h)
     uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
     bool lambda_uniform = true;
     bool lambda_dirty = true;       // host lambdas newer than the device array (uploaded by the next frame)
@@ -54,6 +55,7 @@ struct ocean_ctx {
     float* jraw[MAXD] = {};        // allocated by a chain's first frame of that mode (alloc_jacobian), never by the others
     float* jac0[MAXD] = {};
     unsigned* minmax[MAXD] = {};
+    unsigned* hdone[MAXD] = {};     // [tiles] HEIGHT workgroups of the chain's current frame that have finished (merged x pass: FrameArgs::hdone)
     uint4* done_rec[MAXD] = {};     // [tiles] host-coherent completion records (min key, max key, sequence, 0) written by the last
                                     //   workgroup of a frame's last kernel (ocean_kernels.h: frame_done)
     unsigned* done_ctr[MAXD] = {};  // device counters of that kernel's finished workgroups (two levels: ocean_kernels.h, frame_done)

@@ -158,6 +158,8 @@ struct FrameArgs {
     float* jraw;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: signed d(Dx)/dz = d(Dz)/dx of the same rows
     float* jac0;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: (1 + lambda dDx/dx)(1 + lambda dDz/dz) of the same rows
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
+    unsigned* hdone;         // [tiles]          HEIGHT workgroups of the frame that have finished (reset by the z pass): what the DISP workgroups
+                             //                  of a merged x pass wait for (k_xpass_b, xb_roles bit 2)
     uint4* done_rec;         // [tiles]          host-coherent completion records (min key, max key, frame_seq, 0), written by the
                              //                  displacement pass's last workgroup (frame_done)
     unsigned* done_ctr;      // [1]              workgroups of the displacement pass that have finished (the last one resets it)
@@ -176,7 +178,8 @@ struct FrameArgs {
     int zmask;               // z pass: the transforms this launch runs -- bit 0 pair 0, bit 1 pair 1, bit 2 pair 2, bit 3 the height (pair 3 in the
                              // Jacobian mode).  15 = all (one z pass per frame); the split frame order (launch_frame) runs {height, pair 0} and
                              // {pair 1, pair 2} as two launches, each animating the spectrum for itself
-    int xb_roles;            // k_xpass_b: bit 0 the HEIGHT workgroups, bit 1 the NORMAL workgroups (3 = both in one launch)
+    int xb_roles;            // k_xpass_b: bit 0 the HEIGHT workgroups, bit 1 the NORMAL workgroups (3 = both in one launch), bit 2 the DISP
+                             // workgroups as well (7 = the merged x pass: the whole x axis in one launch, no k_xpass_disp)
     int rec_mode;            // completion records of this launch: 0 none, 1 block 0 writes them early (untracked frame: the stream tells when it
                              // has finished), 2 the last workgroup to finish writes them (frame_done; tracked frame) -- the frame's LAST launch
 };
@@ -976,6 +979,7 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
         a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
+        a.hdone[tile] = 0u;                                   // (merged x pass: its DISP workgroups count the HEIGHT workgroups up from here)
     }
     __syncthreads();
     const float sm0 = raw[0];
@@ -1162,6 +1166,7 @@ __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs 
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
         a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
         a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
+        a.hdone[tile] = 0u;                                   // (merged x pass: its DISP workgroups count the HEIGHT workgroups up from here)
     }
     float kzr[P::r[0]];                                   // kz of this thread's first-stage inputs (behind phase 1: the registers are free by now)
 #pragma unroll
@@ -1201,6 +1206,27 @@ template <int N, int ZW = 1> constexpr size_t zpass_lds_bytes()
     return sizeof(c32) * fft_lds_elems<N, zpass_columns<N>()>() + sizeof(float) * 2 * N;
 }
 
+
+// ---- hand-off inside one launch (the merged x pass) ------------------------------------------
+// The XCDs' L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores: what one workgroup hands to
+// another INSIDE a launch travels write-through -- every store of the handed-off bytes an agent-scope relaxed atomic store (`sc1`: it
+// leaves the XCD's L2 at once, no release of the whole L2 needed), every load of them an agent-scope relaxed atomic load (`sc1`: served
+// past the L1) -- and is announced by ONE lane's agent-scope atomic add behind every storing wave's s_waitcnt vmcnt(0) and the
+// workgroup's barrier; the consumer polls the counter with such a load from one lane, then joins a workgroup barrier
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": valid forms, the table's first row).
+__device__ __forceinline__ void store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned load_wt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane waits until *ctr has reached `target` (bounded: 20 ms -- a producer that never arrives must not hang the device; the frame is
+// then wrong and the next stream operation still completes), then the workgroup's barrier
+__device__ __forceinline__ void wait_counter(const unsigned* ctr, unsigned target, int tid)
+{
+    if (tid == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (load_wt(ctr) < target && (wall_clock64() - t0) < 2000000ull) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+}
 
 // ---- x-pass helpers ------------------------------------------------------------------
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the
@@ -1345,12 +1371,14 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     // a launch holds the HEIGHT workgroups, the NORMAL workgroups or (usually) both: a.xb_roles; bx = the index in the full grid
     const int bx = (int)blockIdx.x + (a.xb_roles == 2 ? HB : 0);
 
+    // (the roles are lambdas: every workgroup of a launch, whatever its role, ends in frame_records)
+    auto pair3_role = [&]() {
     if constexpr (JAC) {
         // ---- PAIR-3 workgroup (OCEAN_MODE_JACOBIAN): the height travels as the real part of pair 3 with the cross
         // derivative as its imaginary part, so C rows per workgroup like every pair (not 2 C real rows): raw signed
         // height and cross derivative of rows u0 .. u0+C-1 out (both even: the mirrored rows hold the same values),
         // global min/max of the height.
-        if (bx < HB) {
+        {
             constexpr int NW = (T + 63) / 64;
             float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
             const int u0 = xcd_swizzle(bx, HB) * C;
@@ -1384,10 +1412,14 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
                 atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
                 atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
             }
-            return;
         }
     }
-    if (!JAC && bx < HB) {
+    };
+    // ---- HEIGHT workgroup: C transforms of two real rows each, raw signed heights out, global min / max by atomics.  In a merged x pass
+    // (xb_roles bit 2) the DISP workgroups of the same launch read those rows and the final min / max: the rows are stored write-through
+    // and the workgroup announces itself on a.hdone behind them (store_wt / wait_counter above).
+    auto height_role = [&]() {
+        const bool merged = (a.xb_roles & 4) != 0;
         constexpr int NW = (T + 63) / 64;
         float* red = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, C>());
         const int u0 = xcd_swizzle(bx, HB) * 2 * C;
@@ -1418,8 +1450,13 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             const float ha = s * v.x, hb = -s * v.y;
             if (u <= N / 2) { vmin = fminf(vmin, ha); vmax = fmaxf(vmax, ha); }
             if (u + 1 <= N / 2) { vmin = fminf(vmin, hb); vmax = fmaxf(vmax, hb); }
-            at32(hraw, hraw_index(N, p, u)) = ha;
-            at32(hraw, hraw_index(N, p, u + 1)) = hb;
+            if (merged) {
+                store_wt(&at32(hraw, hraw_index(N, p, u)), ha);
+                store_wt(&at32(hraw, hraw_index(N, p, u + 1)), hb);
+            } else {
+                at32(hraw, hraw_index(N, p, u)) = ha;
+                at32(hraw, hraw_index(N, p, u + 1)) = hb;
+            }
         };
         // the group of row N/2 holds one valid row: ONE transform (rows N/2 and N/2 + 1) instead of C
         if constexpr (xpass_single_row_group<N, C>()) {
@@ -1445,8 +1482,13 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
             atomicMin(a.minmax + 2 * tile + 0, float_key(vmin));
             atomicMax(a.minmax + 2 * tile + 1, float_key(vmax));
         }
-        return;
-    }
+        if (merged) {
+            // every wave's write-through stores (and lane 0's two atomics) have been taken, then ONE lane counts the workgroup in
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(a.hdone + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 
     // ---- NORMAL workgroup ------------------------------------------------------------
     // (writing the two halves of a texel separately -- 8-byte stores, no registers held
@@ -1564,8 +1606,56 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
         batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
     }
     };
-    normal_role();
-    frame_records<T>(a, reinterpret_cast<unsigned*>(smem), tid, bx == HB);
+    // ---- DISP workgroup of a merged x pass (xb_roles bit 2; never in the Jacobian mode): pair 0 -> displacement-map rows u0 .. u0+C-1, like
+    // k_xpass_disp, in the SAME launch as the HEIGHT workgroups whose rows and min / max it needs.  It transforms at once and holds the
+    // results; only then does it wait for the tile's HEIGHT workgroups (dispatched before it: lower block indices, and they wait for
+    // nobody, so the wait cannot deadlock whatever is resident), reads its raw heights and the final keys write-through, and stores.
+    // The arithmetic per texel is k_xpass_disp's: the same bits.
+    auto disp_role = [&]() {
+        if constexpr (!JAC) {
+            using LSD = LastStage<N, C, T, P, LM>;
+            const int u0 = xcd_swizzle(bx - HB - NB, NB) * C;
+            const float2* __restrict__ z0 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.z) + (size_t)tile * HF::Z_TILE * (Z16 ? 4 : 8));
+            [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
+            const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
+            float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
+            c32 dheld[LSD::IT][LSD::RL];
+            if (a.mode != 2) {
+                auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z0, nf, u0 + c, -1.0f, uu); };
+                auto out = [&](int, int, c32 v, int u, int i) { dheld[u][i] = v; };
+                batch_fft<N, C, T, P>(fbuf, twr, tid, in, out);
+            } else {
+#pragma unroll
+                for (int u = 0; u < LSD::IT; ++u)
+#pragma unroll
+                    for (int i = 0; i < LSD::RL; ++i) dheld[u][i] = make_float2(0.0f, 0.0f);
+            }
+            wait_counter(a.hdone + tile, (unsigned)HB, tid);
+            const unsigned kmn = load_wt(a.minmax + 2 * tile + 0), kmx = load_wt(a.minmax + 2 * tile + 1);      // final: every HEIGHT workgroup has counted itself in
+            const float mn = key_float(kmn), mx = key_float(kmx);
+            const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
+            const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
+            for_each_output<LSD, T>(tid, [&](int p, int c, int u, int i) {
+#pragma clang fp contract(off)          // as in k_xpass_disp
+                const int q = u0 + c;
+                if (q > N / 2) return;
+                const float hv = load_wt(&at32(hraw, hraw_index(N, p, q)));
+                const float sg = ((p + q) & 1) ? -1.0f : 1.0f;
+                const c32 v = dheld[u][i];
+                const float4 o = make_float4(sg * lambda * v.x, hv * inv_a, sg * lambda * v.y, 1.0f);
+                store_map<NTS>(disp, (unsigned)(q * N + p), o);
+                if (q != 0 && q != N / 2)       // mirror: the displacements are odd, the height even
+                    store_map<NTS>(disp, (unsigned)((N - q) * N + ((N - p) & (N - 1))), make_float4(-o.x, o.y, -o.z, 1.0f));
+            });
+        }
+    };
+    const bool merged_launch = (a.xb_roles & 4) != 0;
+    if (bx < HB) { if constexpr (JAC) pair3_role(); else height_role(); }
+    else if (!JAC && merged_launch && bx >= HB + NB) disp_role();
+    else normal_role();
+    // the launch's records: the early form needs the final height keys -- the first NORMAL workgroup of a launch behind the HEIGHT
+    // workgroups' launch (split order), the first DISP workgroup of a merged launch (it has waited for them)
+    frame_records<T>(a, reinterpret_cast<unsigned*>(smem), tid, merged_launch ? bx == HB + NB : bx == HB);
 }
 
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>

@@ -25,6 +25,9 @@ static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
     else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
+// tile sizes whose single-tile frames run the merged x pass (measured: profiles/r05_small_tile_experiments.txt)
+template <int N> constexpr bool xmerge_pays() { return N <= 512; }
+
 template <int N>
 static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
                                hipStream_t st, hipEvent_t* marks /* 2 x OCEAN_MAX_LAUNCHES events (start, stop per launch) or null */)
@@ -131,6 +134,18 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     {   const char* const fo = getenv("OCEAN_FRAME_ORDER");       // (read per frame: tools/ab_order.py flips it between passes)
         split = fo && atoi(fo) == 2 && (c1 || zw2) && (a.mode == 0 || a.mode == 1); }
 #endif
+    // Merged x pass (round 5): HEIGHT, NORMAL and DISP workgroups in ONE launch of k_xpass_b (xb_roles = 7) instead of k_xpass_b + k_xpass_disp.
+    // The DISP workgroups transform pair 0 at once and wait for the tile's HEIGHT workgroups only before their stores (raw heights handed over
+    // write-through, ocean_kernels.h: store_wt / wait_counter): a small single tile is three short DEPENDENT latency chains
+    // (profiles/r02_small_tile_experiments.txt item 0), and this runs the third one beside the second.  Where every workgroup of the launch
+    // is resident at once, one per compute unit (the regime the hand-off recipe is measured for: MI355X_MICROARCH.md), a single tile, not
+    // the Jacobian mode (its displacement pass also needs the NORMAL workgroups' product plane).  Same arithmetic per texel: same bits.
+    bool merged_x = xmerge_pays<N>() && tiles == 1 && a.mode != 3 && !split && c->merged_x &&
+                    (hb_b + 2u * nb) <= (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
+#ifdef OCEAN_DEVELOPER
+    {   const char* const xm = getenv("OCEAN_XMERGE");            // 0 / 1: force (any size, any batch; still not the Jacobian mode)
+        if (xm) merged_x = atoi(xm) != 0 && a.mode != 3 && !split; }
+#endif
     int launches = 0;
     auto next_marks = [&](int kernel) -> hipEvent_t* {      // the event pair of the frame's next launch; remembers which kernel it times
         c->launch_kernel[launches] = kernel;
@@ -188,7 +203,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         do { if (stream_maps & 8) OCEAN_XPASS2(kern, grid, lds, ev, nts, true, args);                                 \
              else OCEAN_XPASS2(kern, grid, lds, ev, nts, false, args); } while (0)
     auto launch_xb = [&](int roles, int rec_mode) {
-        dim3 gb((roles & 1 ? hb : 0u) + (roles & 2 ? nb : 0u), tiles);
+        dim3 gb((roles & 1 ? hb : 0u) + (roles & 2 ? nb : 0u) + (roles & 4 ? nb : 0u), tiles);
 #ifdef OCEAN_XBGRID
         if (const char* ev = getenv("OCEAN_DEBUG_XB_GRID")) gb.x = (unsigned)atoi(ev);   // diagnostic: partial grid (results wrong)
 #endif
@@ -198,7 +213,12 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             li.per_workgroup = C;
             li.lds_bytes = (uint32_t)lds_b;
             li.flags = ((stream_maps & 1) ? OCEAN_LAUNCH_NT_MAPS : 0u) | ((stream_maps & 8) ? OCEAN_LAUNCH_HALF_INTER : 0u) |
-                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | (ramp_b ? OCEAN_LAUNCH_STAGGERED_START : 0u) | (split ? OCEAN_LAUNCH_SPLIT_ORDER : 0u);
+                       (jac ? OCEAN_LAUNCH_JACOBIAN : 0u) | (ramp_b ? OCEAN_LAUNCH_STAGGERED_START : 0u) | (split ? OCEAN_LAUNCH_SPLIT_ORDER : 0u) |
+                       ((roles & 4) ? OCEAN_LAUNCH_MERGED_X : 0u);
+            if (roles & 4) {                     // no k_xpass_disp this frame: its record describes the launch that did its work
+                c->last_launch[2] = li;
+                c->last_launch[2].flags = (li.flags & ~(uint32_t)OCEAN_LAUNCH_NT_MAPS) | ((stream_maps & 2) ? OCEAN_LAUNCH_NT_MAPS : 0u);
+            }
         }
         hipEvent_t* mb = next_marks(1);
 #ifdef OCEAN_XB_TRACE
@@ -240,11 +260,15 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if (getenv("OCEAN_DEBUG_ONLY_ZPASS")) return hipGetLastError();
         arm(1);
 #endif
-        launch_xb(3, 0);
+        if (merged_x) {
+            launch_xb(7, rec_last);
+        } else {
+            launch_xb(3, 0);
 #ifdef OCEAN_STAMPS
-        arm(2);
+            arm(2);
 #endif
-        launch_xd(rec_last);
+            launch_xd(rec_last);
+        }
     } else {
         if ((e = launch_z(8 | 1)) != hipSuccess) return e;
         if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;
