@@ -318,7 +318,9 @@ template <int N, int C, int T, class P, int LM = 0> struct TwiddleRegs {
     }
     c32 w[P::S][itmax()];
 
-    template <int STAGE, int NS>
+    // TS: stride in the table -- a table of exp(+2 pi i k / (TS N)) serves a transform of length N at every TS-th entry (the
+    // half-size transform of the real height column reads the tile size's table with TS = 2: ocean_kernels.h, zpass_height_half)
+    template <int STAGE, int NS, int TS = 1>
     __device__ __forceinline__ void load_from(const c32* __restrict__ tw, int tid)
     {
         constexpr int R = P::r[STAGE];
@@ -332,12 +334,13 @@ template <int N, int C, int T, class P, int LM = 0> struct TwiddleRegs {
                 int c_unused;
                 last_stage_map<N, C, R, LM>(wi < ITEMS ? wi : 0, c_unused, j);
             }
-            if constexpr (NS > 1) w[STAGE][u] = tw[(j % NS) * (N / (NS * R))];
+            if constexpr (NS > 1) w[STAGE][u] = tw[TS * ((j % NS) * (N / (NS * R)))];
             else w[STAGE][u] = make_float2(1.f, 0.f);
         }
-        if constexpr (STAGE + 1 < P::S) load_from<STAGE + 1, NS * R>(tw, tid);
+        if constexpr (STAGE + 1 < P::S) load_from<STAGE + 1, NS * R, TS>(tw, tid);
     }
     __device__ __forceinline__ void load(const c32* __restrict__ tw, int tid) { load_from<0, 1>(tw, tid); }
+    template <int TS> __device__ __forceinline__ void load_strided(const c32* __restrict__ tw, int tid) { load_from<0, 1, TS>(tw, tid); }
 };
 
 // One Stockham stage over the whole batch.
