@@ -382,11 +382,13 @@ int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [
  * THIS device (grid <= compute units x workgroups per unit); on != 0 (default) allows it, 0 switches it off for the context -- for a device
  * shared with other work, where a workgroup's wait is simply lost.  Frames are bit-identical either way.                                    */
 int ocean_set_start_ramp(ocean_t* ctx, int on);
-/* The x axis in ONE launch (round 5): frames of a single small tile (N <= 512) run their height, normal-map and displacement workgroups
- * as one grid -- the displacement workgroups transform at once and wait for the tile's height workgroups only before their stores -- two
- * launches per frame instead of three (512^2: see DESIGN.md).  Applied only where every workgroup of that grid is resident at once, one per
- * compute unit; never in OCEAN_MODE_JACOBIAN.  on != 0 (default) allows it, 0 keeps the three-launch frame.  Bit-identical either way;
- * ocean_last_launch marks such a frame with OCEAN_LAUNCH_MERGED_X on idx 1 and 2 (the same launch).                                      */
+/* The x axis in ONE launch (round 5): frames of a single small tile run their height, normal-map and displacement workgroups as one grid --
+ * the displacement workgroups transform at once and wait for the tile's height workgroups only before their stores -- two launches per frame
+ * instead of three.  Applied where it was measured to pay (pipelined frames up to 512^2, which are bound by the rate of launches: 13-15 -> 8 us
+ * per frame at depth 4; serial frames up to 128^2 only -- from 256^2 up the in-launch hand-off costs more than the kernel boundary it replaces)
+ * and only where every workgroup of that grid is resident at once, one per compute unit; never in OCEAN_MODE_JACOBIAN.  on != 0 (default)
+ * allows it, 0 keeps the three-launch frame.  Bit-identical either way; ocean_last_launch marks such a frame with OCEAN_LAUNCH_MERGED_X on
+ * idx 1 and 2 (the same launch).                                                                                                          */
 int ocean_set_merged_xpass(ocean_t* ctx, int on);
 
 /* ---- introspection for tests and the bench -------------------------------- */

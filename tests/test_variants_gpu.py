@@ -170,7 +170,7 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
             stag = A.OCEAN_LAUNCH_STAGGERED_START                  # not a variant: the same instantiation, started differently
             # nor is the merged x pass (round 5): k_xpass_b's instantiation with its DISP workgroups in the same launch -- single small tiles, not the Jacobian mode
             merged = A.OCEAN_LAUNCH_MERGED_X
-            assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= 512 and tiles == 1 and not jac), what
+            assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= (128 if depth == 1 else 512) and tiles == 1 and not jac), what
             if xb["flags"] & merged:
                 assert xb["grid_x"] == xd["grid_x"] and (xb["flags"] & ~A.OCEAN_LAUNCH_NT_MAPS) == (xd["flags"] & ~A.OCEAN_LAUNCH_NT_MAPS), what
             assert not any(li["flags"] & A.OCEAN_LAUNCH_SPLIT_ORDER for li in (z, xb, xd)), what      # (developer builds only: profiles/r05_4096_experiments.txt)
@@ -297,7 +297,10 @@ def test_merged_x_pass_delivers_the_bits_of_the_three_launch_frame(n, oracles):
         d1, q1, h1, a1, l1 = frames(False, mode, bits, depth, sync)
         d2, q2, h2, a2, l2 = frames(True, mode, bits, depth, sync)
         assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l1), what
-        assert l2[1]["flags"] & A.OCEAN_LAUNCH_MERGED_X and l2[2]["flags"] & A.OCEAN_LAUNCH_MERGED_X and l2[1]["grid_x"] > l1[1]["grid_x"], what
+        if n > 128 and depth == 1:          # serial frames from 256^2 up keep three launches (the hand-off costs more than the boundary it replaces)
+            assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l2), what
+        else:
+            assert l2[1]["flags"] & A.OCEAN_LAUNCH_MERGED_X and l2[2]["flags"] & A.OCEAN_LAUNCH_MERGED_X and l2[1]["grid_x"] > l1[1]["grid_x"], what
         assert np.array_equal(d1, d2) and np.array_equal(q1, q2) and h1 == h2, what
         if sync:
             assert np.array_equal(a1, a2) and h2[0][0] == float(a2[0]), what

@@ -636,28 +636,29 @@ __device__ __forceinline__ void real_split(c32 zk, c32 zm, c32 w, c32& yk, c32& 
 }
 
 // C columns (c1 form: 1; two-column form: 2) by the T threads of the workgroup.  spx[c]: column c's S+ table [N floats] = the exchange's M
-// complex slots; splus(e, c): S+ of element e of column c (read from that table -- or formed from G on the Nyquist column).
+// complex slots; splus(e, c): S+ of element e of column c (read from that table -- or formed from G on the Nyquist column).  A thread's
+// split items (column c, pair t) are the (c, j) of its last-stage work items: wk[u] = w^t = exp(+2 pi i t / N) of item u comes from the
+// caller -- it IS the full-size plan's last-stage base twiddle of the same thread where the forms below say so, a table entry otherwise.
 template <int N, int T, int C, bool ZNT, bool Z16, class TWH, class Splus>
-__device__ __forceinline__ void zpass_height_half(const FrameArgs& a, c32* fbuf, float* const (&spx)[C], TWH& twh, int tid, float2* __restrict__ zh,
+__device__ __forceinline__ void zpass_height_half(const FrameArgs& a, c32* fbuf, float* const (&spx)[C], TWH& twh,
+                                                  const c32 (&wk)[(C * (N / 8) + T - 1) / T], int tid, float2* __restrict__ zh,
                                                   const int (&cols)[C], float su, Splus&& splus)
 {
     using HF = Half<N>;
     using PH = HalfHeightPlan<N>;
+    using LSH = LastStage<N / 2, C, T, PH>;
     constexpr int M = N / 2, Q = M / 4;                    // Q pairs (k, k') per column
-    static_assert((C * Q) % T == 0 || C * Q < T, "split items");
-    constexpr int IT = (C * Q + T - 1) / T;
-    c32 wk[IT];                                            // w^t of this thread's pairs: fetched now, used behind the transform
-#pragma unroll
-    for (int u = 0; u < IT; ++u) wk[u] = a.tw[(tid + u * T) % Q];
+    static_assert(PH::last == 4 && LSH::ITEMS == C * Q, "one split item per last-stage work item");
     auto in = [&](int n, int c, int, int) -> c32 { return make_float2(splus(2 * n, c), splus(2 * n + 1, c)); };
     auto out = [&](int p, int c, c32 v, int, int) { reinterpret_cast<c32*>(spx[c])[p] = v; };
     batch_fft<M, C, T, PH>(fbuf, twh, tid, in, out);
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < IT; ++u) {
+    for (int u = 0; u < LSH::IT; ++u) {
         const int w = tid + u * T;
-        if (C * Q % T == 0 || w < C * Q) {
-            const int c = w / Q, t = w % Q;
+        if (!LSH::GUARD || w < LSH::ITEMS) {
+            int c, t;
+            LSH::map(w, c, t);
             const c32* __restrict__ zx = reinterpret_cast<const c32*>(spx[c]);
             const int col = cols[c];
             c32 y0, y1;
@@ -675,9 +676,38 @@ __device__ __forceinline__ void zpass_height_half(const FrameArgs& a, c32* fbuf,
         }
     }
 }
-// (the twiddle registers of that transform: the tile size's table at every second entry)
+// The twiddle registers of that transform and w^t of the split step.  A thread's base twiddle of a stage is exp(+2 pi i (j % NS) / (NS R)):
+// the half-size plans run the tile size's own first stages, so where a stage of theirs has the NS of the full-size plan's stage it is that
+// stage's register (same radix) or its square (half the radix), with no load at all -- a load here sits on every workgroup's critical path,
+// and a single resident round (2048^2) is as long as its workgroups' chains:
+//     2048: full 8.8.8.4 (NS 1, 8, 64, 512), half 8.8.4.4 (NS 1, 8, 64, 256):  w1 = W1, w2 = W2^2, w3 = W3^2 (j < 256), w^t = W3
+//     4096: full 8.8.8.8 (NS 1, 8, 64, 512), half 8.8.8.4 (NS 1, 8, 64, 512):  w1 = W1, w2 = W2,   w3 = W3^2,           w^t = W3
+// for the forms whose work-item mapping the half-size transform shares (single-transform batches; the two-column form, whose first
+// last-stage item is the half-size one's).  from_table: the general way (the lone columns of the two-column kernel).
 template <int N, int T, int C> struct HalfHeightTwiddles {
     using type = TwiddleRegs<N / 2, C, T, HalfHeightPlan<N>>;
+    static constexpr int ITW = (C * (N / 8) + T - 1) / T;
+    template <class TWF>
+    static __device__ __forceinline__ void from_full(const TWF& full, type& h, c32 (&wk)[ITW])
+    {
+        static_assert(ITW == 1 && (N == 2048 || N == 4096), "forms with one split item per thread");
+        h.w[0][0] = make_float2(1.f, 0.f);
+        h.w[1][0] = full.w[1][0];
+        h.w[2][0] = N == 2048 ? cmul(full.w[2][0], full.w[2][0]) : full.w[2][0];
+        h.w[3][0] = cmul(full.w[3][0], full.w[3][0]);
+        wk[0] = full.w[3][0];
+    }
+    static __device__ __forceinline__ void from_table(const c32* __restrict__ tw, int tid, type& h, c32 (&wk)[ITW])
+    {
+        using LSH = LastStage<N / 2, C, T, HalfHeightPlan<N>>;
+        h.template load_strided<2>(tw, tid);
+#pragma unroll
+        for (int u = 0; u < ITW; ++u) {
+            int c, t;
+            LSH::map((tid + u * T) < LSH::ITEMS ? tid + u * T : 0, c, t);
+            wk[u] = tw[t];
+        }
+    }
 };
 
 // The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
@@ -858,12 +888,14 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             // column's bits do not depend on the form that happened to run it (here: the lone columns 0, 1 and N/2 of the two-column kernel)
             if (!jac) {
                 __syncthreads();                    // the batch's last stage has read the image
-                typename HalfHeightTwiddles<N, T, 1>::type twh;
-                twh.template load_strided<2>(a.tw, tid);
+                using HT = HalfHeightTwiddles<N, T, 1>;
+                typename HT::type twh;
+                c32 wk[HT::ITW];
+                HT::from_table(a.tw, tid, twh, wk);
                 float* const spx[1] = {const_cast<float*>(sp)};
                 const int cols[1] = {nb};
-                zpass_height_half<N, T, 1, ZNT, Z16>(a, fbuf, spx, twh, tid, zh, cols, su,
-                                                      [&](int e, int) { float sv, tx, tz; fetch(e, sv, tx, tz); return sv; });
+                zpass_height_half<N, T, 1, ZNT, Z16>(a, fbuf, spx, twh, wk, tid, zh, cols, su,
+                                                      [&](int e, int) { asm("" : "+v"(e)); float sv, tx, tz; fetch(e, sv, tx, tz); return sv; });
             }
         }
     }
@@ -971,11 +1003,13 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
     }
     if constexpr (zpass_half_height<N>()) {
         if ((a.zmask & 8) && !jac) {      // both columns' heights as real-input transforms (zpass_height_half: the single-transform form's bits)
-            typename HalfHeightTwiddles<N, T, 2>::type twh;
-            twh.template load_strided<2>(a.tw, tid);
+            using HT = HalfHeightTwiddles<N, T, 2>;
+            typename HT::type twh;
+            c32 wk[HT::ITW];
+            HT::from_full(twr, twh, wk);
             float* const spx[2] = {sp0, sp1};
             const int cols[2] = {nb0, nb0 + 1};
-            zpass_height_half<N, T, 2, ZNT, Z16>(a, fbuf, spx, twh, tid, zh, cols, su, [&](int e, int c) { return c ? sp1[e] : sp0[e]; });
+            zpass_height_half<N, T, 2, ZNT, Z16>(a, fbuf, spx, twh, wk, tid, zh, cols, su, [&](int e, int c) { return c ? sp1[e] : sp0[e]; });
             return;
         }
     }
@@ -1202,12 +1236,18 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
     }
     if constexpr (zpass_half_height<N>()) {
         if ((a.zmask & 8) && !jac) {      // the height as a real-input transform: half the size + one split step (zpass_height_half)
-            typename HalfHeightTwiddles<N, T, 1>::type twh;
-            twh.template load_strided<2>(a.tw, tid);
+            using HT = HalfHeightTwiddles<N, T, 1>;
+            typename HT::type twh;
+            c32 wk[HT::ITW];
+            HT::from_full(twr, twh, wk);
             float* const spx[1] = {const_cast<float*>(sp)};
             const int cols[1] = {nb};
-            zpass_height_half<N, T, 1, ZNT, Z16>(a, fbuf, spx, twh, tid, zh, cols, su,
-                                                  [&](int e, int) { float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc); return sv; });
+            zpass_height_half<N, T, 1, ZNT, Z16>(a, fbuf, spx, twh, wk, tid, zh, cols, su,
+                                                  [&](int e, int) {
+                                                      // (opaque index: otherwise the Nyquist column's mirror index (N - e) % N is recognised as phase 1's and kept
+                                                      //  alive -- through a spill -- across the whole kernel instead of being recomputed in two instructions)
+                                                      asm("" : "+v"(e));
+                                                      float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc); return sv; });
             return;
         }
     }

@@ -25,8 +25,8 @@ static void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
     else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
-// tile sizes whose single-tile frames run the merged x pass (measured: profiles/r05_small_tile_experiments.txt)
-template <int N> constexpr bool xmerge_pays() { return N <= 512; }
+// tile sizes whose single-tile frames run the merged x pass (measured: profiles/r05_small_tile_experiments.txt); alone = a serial frame
+template <int N> constexpr bool xmerge_pays(bool alone) { return alone ? N <= 128 : N <= 512; }
 
 template <int N>
 static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps /* bit 0: normal map, bit 1: displacement map, bit 2: intermediates */,
@@ -140,7 +140,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // (profiles/r02_small_tile_experiments.txt item 0), and this runs the third one beside the second.  Where every workgroup of the launch
     // is resident at once, one per compute unit (the regime the hand-off recipe is measured for: MI355X_MICROARCH.md), a single tile, not
     // the Jacobian mode (its displacement pass also needs the NORMAL workgroups' product plane).  Same arithmetic per texel: same bits.
-    bool merged_x = xmerge_pays<N>() && tiles == 1 && a.mode != 3 && !split && c->merged_x &&
+    // Where it pays (profiles/r05_small_tile_experiments.txt): a SERIAL frame only up to 128^2 (64^2: 12.8 -> 11.6 us; from 256^2 up the
+    // hand-off's three dependent memory round trips cost more than the kernel boundary they replace: 512^2 16.6 -> 18.2 us); PIPELINED frames
+    // of one tile up to 512^2, which are bound by the rate of launches, not by any kernel (512^2, depth 4: 13.2-14.9 -> 8.0 us per frame).
+    bool merged_x = xmerge_pays<N>(alone) && tiles == 1 && a.mode != 3 && !split && c->merged_x &&
                     (hb_b + 2u * nb) <= (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
 #ifdef OCEAN_DEVELOPER
     {   const char* const xm = getenv("OCEAN_XMERGE");            // 0 / 1: force (any size, any batch; still not the Jacobian mode)
