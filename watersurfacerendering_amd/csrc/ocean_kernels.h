@@ -437,8 +437,12 @@ __device__ __forceinline__ void spectrum_form(const FrameArgs& a, F&& f)
 #ifndef OCEAN_SPEC_NT_MIN
 #define OCEAN_SPEC_NT_MIN 4096
 #endif
-template <int N> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC_NT_MIN; }
-template <int N, bool H16, bool W16>
+#ifdef OCEAN_SPEC_NT_ALWAYS
+template <int N, bool ZNT> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC_NT_MIN; }
+#else
+template <int N, bool ZNT> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC_NT_MIN && !ZNT; }
+#endif
+template <int N, bool H16, bool W16, bool ZNT = false>
 __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
                                                 float4& ha, float2& hb0, float2& hb1, float2& w)
 {
@@ -450,7 +454,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
     ha = make_float4(1.f + g, 2.f, 3.f, 4.f); hb0 = make_float2(0.5f, 1.5f); hb1 = make_float2(2.5f, 3.5f); w = make_float2(0.5f, 0.25f);
     return;
 #endif
-    if constexpr (spectrum_nt<N>() && !H16 && W16) {
+    if constexpr (spectrum_nt<N, ZNT>() && !H16 && W16) {
         // beyond the memory-side cache (4096^2: 151 MB of spectrum, read once per z pass): streamed past it, so that the intermediates
         // -- written here, re-read by the x pass right behind -- are what stays resident (ocean_launch.h: the split frame order)
         typedef float nt4 __attribute__((ext_vector_type(4)));
@@ -620,8 +624,12 @@ template <int N, int T, class P, int ZC, bool Z16> struct ZStore {
 template <int N> struct HalfHeightPlan;                                   // radix plan of the N/2-point transform (tools/check_lds_offsets.py reads these)
 template <> struct HalfHeightPlan<2048> : Radices<8, 8, 4, 4> {};
 template <> struct HalfHeightPlan<4096> : Radices<8, 8, 8, 4> {};
+// MEASURED AND NOT ADOPTED (profiles/r05_zpass_experiments.txt): 2048^2 z pass 21.7-21.8 us either way, 4096^2 93.7-98.7 against 92.7-94.3 us
+// with the full-size transform -- the split step's extra exchange and barrier lengthen every workgroup's chain by about what the smaller
+// transform saves, and the z pass is bound by those chains, not by butterfly throughput.  The form stays selectable for developer builds
+// (make variant DEFS=-DOCEAN_HALF_HEIGHT_MIN=2048); the shipped library runs the full-size height transform at every size.
 #ifndef OCEAN_HALF_HEIGHT_MIN
-#define OCEAN_HALF_HEIGHT_MIN 2048
+#define OCEAN_HALF_HEIGHT_MIN 8192
 #endif
 template <int N> constexpr bool zpass_half_height() { return N >= OCEAN_HALF_HEIGHT_MIN && N >= 2048; }
 
@@ -693,8 +701,9 @@ template <int N, int T, int C> struct HalfHeightTwiddles {
         static_assert(ITW == 1 && (N == 2048 || N == 4096), "forms with one split item per thread");
         h.w[0][0] = make_float2(1.f, 0.f);
         h.w[1][0] = full.w[1][0];
-        h.w[2][0] = N == 2048 ? cmul(full.w[2][0], full.w[2][0]) : full.w[2][0];
-        h.w[3][0] = cmul(full.w[3][0], full.w[3][0]);
+        // (squares through the packed multiply: instructions of their own, the same bits in every kernel that derives them)
+        h.w[2][0] = N == 2048 ? toc(pk_cmul(tov(full.w[2][0]), tov(full.w[2][0]))) : full.w[2][0];
+        h.w[3][0] = toc(pk_cmul(tov(full.w[3][0]), tov(full.w[3][0])));
         wk[0] = full.w[3][0];
     }
     static __device__ __forceinline__ void from_table(const c32* __restrict__ tw, int tid, type& h, c32 (&wk)[ITW])
@@ -931,7 +940,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int it = tid + (ub + u) * T;
-                zpass_load_pair<N, H16, W16>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                zpass_load_pair<N, H16, W16, ZNT>(a, tile, nb0 + it / (N / 2), 2 * (it % (N / 2)), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -1091,7 +1100,7 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int it = tid + (ub + u) * T;
-                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N, H16, W16>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                if (PAIRS % T == 0 || it < PAIRS) zpass_load_pair<N, H16, W16, ZNT>(a, tile, nb, 2 * it, h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -1300,7 +1309,7 @@ __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs 
             float2 hb0[PB], hb1[PB], wv[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u)
-                zpass_load_pair<N, H16, W16>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                zpass_load_pair<N, H16, W16, ZNT>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int n = 2 * (tid + (ub + u) * T);
