@@ -61,11 +61,27 @@ __device__ __forceinline__ void store_nt(float4* p, float4 v)
 // non-temporal), so the x-pass kernels exist in both forms (template flag NTS) and the host
 // picks per launch.  The texel index is turned into a 32-bit byte offset (N <= 4096: < 2^28)
 // so the store addresses as scalar base + vector offset.
+// (developer A/B, profiles/r05_store_policy_experiments.txt: -DOCEAN_MAP_SC1=1 stores the maps of the plain form write-through, `sc1`; =2 those
+//  of the non-temporal form as well; -DOCEAN_Z_SC1 the fp32 intermediates of the plain form)
+__device__ __forceinline__ void store_f4_sc1(float4* base, unsigned byte_off, float4 v)
+{
+    const ocean_f4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
+}
+__device__ __forceinline__ void store_f2_sc1(float2* base, unsigned byte_off, float2 v)
+{
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v t = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_off), "v"(t), "s"(base) : "memory");
+}
 template <bool NTS> __device__ __forceinline__ void store_map(float4* base, unsigned texel, float4 v)
 {
 #ifdef OCEAN_ABL_NOMAPSTORE      // ablation build: the map texels are computed but never written
     asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #else
+#ifdef OCEAN_MAP_SC1
+    if constexpr (!NTS || OCEAN_MAP_SC1 == 2) { store_f4_sc1(base, texel * 16u, v); return; }
+#endif
     float4* p = reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + (texel * 16u));
     if constexpr (NTS) store_nt(p, v);
     else *p = v;
@@ -102,7 +118,11 @@ template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(fl
         const f2nt t = {v.x, v.y};
         __builtin_nontemporal_store(t, reinterpret_cast<f2nt*>(reinterpret_cast<char*>(base) + idx * 8u));
     } else {
+#ifdef OCEAN_Z_SC1
+        store_f2_sc1(base, idx * 8u, v);
+#else
         *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+#endif
     }
 }
 // element idx of an intermediate array as float2 (times `unscale` in the half2 form)
