@@ -1241,7 +1241,7 @@ int ocean_time_frames(ocean_t* c, float t0, float dt, int warmup, int frames, fl
 }
 
 #ifdef OCEAN_XB_TRACE
-// diagnostic build only (tools/xb_trace.py): enable = allocate the trace buffer (the next frames' k_xpass_b fill it); host_out = copy it out
+// diagnostic build only (tools/archive/xb_trace.py): enable = allocate the trace buffer (the next frames' k_xpass_b fill it); host_out = copy it out
 extern "C" int ocean_debug_xb_trace(ocean_t* c, int enable, unsigned long long* host_out, size_t count)
 {
     if (!c) return OCEAN_E_INVALID;

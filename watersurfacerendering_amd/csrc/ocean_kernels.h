@@ -41,7 +41,7 @@
 #include "fft_engine.h"
 
 // Diagnostic builds (never shipped; `make -C csrc variant NAME=x DEFS=...`): -DOCEAN_STAMPS records
-// per-workgroup phase clocks (tools/stamps.py); -DOCEAN_ABL_NOLOAD / _NOSTORE / _NOMAPSTORE / _NOFFT /
+// per-workgroup phase clocks (tools/archive/stamps.py); -DOCEAN_ABL_NOLOAD / _NOSTORE / _NOMAPSTORE / _NOFFT /
 // _NOIN / _SINCOS remove the global loads, the intermediate stores, the map stores, the butterfly
 // arithmetic, the z-pass input arithmetic or the sincos -- results are then wrong on purpose; they
 // only attribute time.
@@ -61,8 +61,9 @@ __device__ __forceinline__ void store_nt(float4* p, float4 v)
 // non-temporal), so the x-pass kernels exist in both forms (template flag NTS) and the host
 // picks per launch.  The texel index is turned into a 32-bit byte offset (N <= 4096: < 2^28)
 // so the store addresses as scalar base + vector offset.
-// (developer A/B, profiles/r05_store_policy_experiments.txt: -DOCEAN_MAP_SC1=1 stores the maps of the plain form write-through, `sc1`; =2 those
-//  of the non-temporal form as well; -DOCEAN_Z_SC1 the fp32 intermediates of the plain form)
+// Write-through (`sc1`) stores: the line leaves the XCD's L2 as it is written.  Adopted for the fp32 intermediates up to 2048 (store_z, WT);
+// measured and rejected for the maps (developer A/B: -DOCEAN_MAP_SC1=1 stores the maps of the plain form that way, =2 those of the
+// non-temporal form as well: k_xpass_disp 16.0 -> 17.6-18.2 us at 2048^2, the pipelined and 4096^2 frames +40 %; profiles/r05_store_policy_experiments.txt).
 __device__ __forceinline__ void store_f4_sc1(float4* base, unsigned byte_off, float4 v)
 {
     const ocean_f4 t = {v.x, v.y, v.z, v.w};
@@ -104,7 +105,16 @@ template <class T> __device__ __forceinline__ const T& at32(const T* base, unsig
 // half2, multiplied first by a per-tile power of two `scale` chosen at ocean_prepare from a time-independent bound
 // of the column sums so that nothing can overflow (k_inter_bounds); the same arrays, half the bytes (14 -> 7 B/texel
 // out of the z pass and into the x pass).  Stated accuracy of that mode: tests/test_parity_gpu.py.
-template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v, float scale = 1.0f, float scale_y = 0.0f)
+// WT = WRITE-THROUGH (round 5, profiles/r05_store_policy_experiments.txt): the fp32 intermediates of the plain form are stored `sc1` -- they leave
+// the XCD's L2 as they are written instead of sitting there dirty until the end-of-kernel release writes everything back in one burst behind
+// the last workgroup; the x pass that reads them runs on whatever XCD its rows land on, so seven reads in eight come through the fabric anyway.
+// 2048^2 serial z pass 21.8-21.9 -> 20.4-20.7 us (x passes unchanged), 512^2 6.5-7.0 -> 6.2-6.6, 8 x 1024^2 36.9-37.2 -> 35.6-36.8; at 4096^2
+// -- several rounds of workgroups, 235 MB -- the same stores cost 6-8 us (90-95 -> 99-100), so up to 2048 only (z_write_through<N>()).
+#ifndef OCEAN_Z_WT_MAX
+#define OCEAN_Z_WT_MAX 2048
+#endif
+template <int N> constexpr bool z_write_through() { return N <= OCEAN_Z_WT_MAX; }
+template <bool ZNT, bool Z16 = false, bool WT = false> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v, float scale = 1.0f, float scale_y = 0.0f)
 {
     if constexpr (Z16) {
         const __half2 h = __floats2half2_rn(v.x * scale, v.y * (scale_y != 0.0f ? scale_y : scale));
@@ -117,12 +127,10 @@ template <bool ZNT, bool Z16 = false> __device__ __forceinline__ void store_z(fl
         typedef float f2nt __attribute__((ext_vector_type(2)));
         const f2nt t = {v.x, v.y};
         __builtin_nontemporal_store(t, reinterpret_cast<f2nt*>(reinterpret_cast<char*>(base) + idx * 8u));
-    } else {
-#ifdef OCEAN_Z_SC1
+    } else if constexpr (WT) {
         store_f2_sc1(base, idx * 8u, v);
-#else
+    } else {
         *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
-#endif
     }
 }
 // element idx of an intermediate array as float2 (times `unscale` in the half2 form)
@@ -135,7 +143,13 @@ template <bool Z16> __device__ __forceinline__ float2 load_z(const float2* base,
         const float2 f = __half22float2(h);
         return make_float2(f.x * unscale, f.y * (unscale_y != 0.0f ? unscale_y : unscale));
     } else {
+#ifdef OCEAN_XLOAD_NT      // developer A/B: the x passes read the intermediates, each element once, with non-temporal loads
+        typedef float f2nt __attribute__((ext_vector_type(2)));
+        const f2nt t = __builtin_nontemporal_load(reinterpret_cast<const f2nt*>(reinterpret_cast<const char*>(base) + idx * 8u));
+        return make_float2(t.x, t.y);
+#else
         return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + idx * 8u);
+#endif
     }
 }
 template <class T> __device__ __forceinline__ T& at32(T* base, unsigned idx)
@@ -691,15 +705,15 @@ __device__ __forceinline__ void zpass_height_half(const FrameArgs& a, c32* fbuf,
             const int col = cols[c];
             c32 y0, y1;
             real_split(zx[t], zx[(M - t) & (M - 1)], wk[u], y0, y1);                         // k = t: rows t and M - t
-            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, t), y0, su);
-            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M - t), y1, su);
+            store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, t), y0, su);
+            store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M - t), y1, su);
             real_split(zx[M / 2 - t], zx[M / 2 + t], make_float2(wk[u].y, wk[u].x), y0, y1);  // k' = M/2 - t: rows M/2 - t and M/2 + t
-            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 2 - t), y0, su);
-            if (t != 0) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 2 + t), y1, su);
+            store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M / 2 - t), y0, su);
+            if (t != 0) store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M / 2 + t), y1, su);
             if (t == 0) {                                                                      // k = M/4: w^(N/8) = (1 + i) / sqrt 2
                 real_split(zx[M / 4], zx[3 * M / 4], make_float2(0.70710678118654752440f, 0.70710678118654752440f), y0, y1);
-                store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 4), y0, su);
-                store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, 3 * M / 4), y1, su);
+                store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M / 4), y0, su);
+                store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, 3 * M / 4), y1, su);
             }
         }
     }
@@ -835,12 +849,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         auto out = [&](int p, int c, c32 v, int u, int i) {
             const unsigned pos = zo.pos(nb, p, u, i);
             if (c == 3) {
-                if (jac) store_z<ZNT, Z16>(z3, pos, v, s3);
-                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);
+                if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, pos, v, s3);
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb, p, u, i), v, su);
                 return;
             }
             if (a.mode == 2) return;
-            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
+            store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
         };
         batch_fft<N, 4, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -866,7 +880,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
-            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
+            store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -903,12 +917,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
+                if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, zo.pos(nb, p, u, i), v, s3);
                 else if constexpr (zpass_half_height<N>()) return;                               // (the height follows below, as the other forms compute it)
-                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
                 return;
             }
-            store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
+            store_z<ZNT, Z16, z_write_through<N>()>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -1010,7 +1024,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<0>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
@@ -1018,7 +1032,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<1>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
     }
@@ -1027,7 +1041,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
             return zpass_input<2>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
         };
-        auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
+        auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
     if constexpr (zpass_half_height<N>()) {
@@ -1049,8 +1063,8 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             return zpass_input<3>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, true, g3);
         };
         auto out = [&](int p, int c, c32 v, int u, int i) {
-            if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb0 + c, p, u, i), v, s3);
-            else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb0 + c, p, u, i), v, su);     // real input: other half is the conjugate
+            if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, zo.pos(nb0 + c, p, u, i), v, s3);
+            else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb0 + c, p, u, i), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
@@ -1243,7 +1257,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb, p, u, i), v, su); };
+            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, zo.pos(nb, p, u, i), v, su); };
             batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
@@ -1251,7 +1265,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
+            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
             batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
     }
@@ -1260,7 +1274,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
         };
-        auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
+        auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
         batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
     if constexpr (zpass_half_height<N>()) {
@@ -1287,8 +1301,8 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return zpass_input<3>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, true, g3);
         };
         auto out = [&](int p, int, c32 v, int u, int i) {
-            if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
-            else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
+            if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, zo.pos(nb, p, u, i), v, s3);
+            else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
@@ -1455,7 +1469,7 @@ __device__ __forceinline__ void for_each_output(int tid, F f)
 // measured slower at every size and removed.)
 // ============================================================================
 #ifdef OCEAN_XB_TRACE
-// diagnostic build only (tools/xb_trace.py, profiles/r03_xpass_trace.txt): per workgroup of the two x passes, where and when it ran --
+// diagnostic build only (tools/archive/xb_trace.py, profiles/r03_xpass_trace.txt): per workgroup of the two x passes, where and when it ran --
 // [record][4] = {start, end (100 MHz wall clock), HW_REG_HW_ID, HW_REG_XCC_ID}; records 0.. = k_xpass_b's workgroups, 512.. = k_xpass_disp's
 static __device__ unsigned long long* g_xb_trace = nullptr;
 struct XbTrace {
