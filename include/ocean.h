@@ -434,6 +434,8 @@ enum {
                                             (serial and pipelined frames with ramps of their own), nowhere else          */
     OCEAN_LAUNCH_SPLIT_ORDER     = 512,  /* developer builds only (never set by the shipped library): the frame ran in the split order of
                                             profiles/r05_4096_experiments.txt -- z pass and k_xpass_b twice, each time half their work        */
+    OCEAN_LAUNCH_WT_INTER        = 2048, /* z pass: fp32 intermediates stored write-through (`sc1`: they leave the XCD's L2 as they are written, no
+                                            end-of-kernel write-back burst) -- serial frames at 1024^2 (batches) and 2048^2, single-transform form */
     OCEAN_LAUNCH_MERGED_X        = 1024  /* not a kernel variant: k_xpass_b ran the displacement workgroups as well (one launch for the whole x axis,
                                             no k_xpass_disp); set on idx 1 and idx 2, which then describe that one launch                   */
 };

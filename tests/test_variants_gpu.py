@@ -141,8 +141,10 @@ def expected_variants(n):
         common = (A.OCEAN_LAUNCH_HALF_INTER if z16 else 0) | (A.OCEAN_LAUNCH_JACOBIAN if jac else 0)
         # ocean_kernels.h: zpass_c1_pays -- 4096^2 always; 2048^2 and batches of 1024^2 unless the intermediates are streamed
         c1 = n == 4096 or (name != "stream" and (n == 2048 or (n == 1024 and tiles >= 2)))
+        # round 5: a SERIAL frame's fp32 intermediates go out write-through in the single-transform form at 1024 and 2048 (ocean_kernels.h: store_z)
+        wt = c1 and name in ("plain", "batch") and n in (1024, 2048) and not z16
         zf = common | (A.OCEAN_LAUNCH_NT_INTER if name == "stream" else 0) | (A.OCEAN_LAUNCH_FP16_SPECTRUM if h16 else 0) | \
-            (A.OCEAN_LAUNCH_FP32_DISPERSION if w32 else 0) | (A.OCEAN_LAUNCH_SINGLE_TRANSFORM if c1 else 0)
+            (A.OCEAN_LAUNCH_FP32_DISPERSION if w32 else 0) | (A.OCEAN_LAUNCH_SINGLE_TRANSFORM if c1 else 0) | (A.OCEAN_LAUNCH_WT_INTER if wt else 0)
         xf = common | (A.OCEAN_LAUNCH_NT_MAPS if name not in ("plain", "batch") else 0)
         zw = 2 if n in (1024, 2048) and name == "stream" else 1
         out.add((n, zf, zw, xf, xf))

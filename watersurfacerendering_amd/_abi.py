@@ -47,6 +47,7 @@ OCEAN_LAUNCH_FP16_SPECTRUM, OCEAN_LAUNCH_FP32_DISPERSION, OCEAN_LAUNCH_SPLIT_LAS
 OCEAN_LAUNCH_STAGGERED_START = 256
 OCEAN_LAUNCH_SPLIT_ORDER = 512      # developer builds only
 OCEAN_LAUNCH_MERGED_X = 1024
+OCEAN_LAUNCH_WT_INTER = 2048
 
 
 class OceanError(RuntimeError):

@@ -32,6 +32,7 @@ struct ocean_ctx {
     int last_set = 0;
     int cu_count = 0;               // compute units of the device
     bool start_ramp = true;         // ocean_set_start_ramp: the staggered start may be used where it applies (ocean_launch.h)
+    bool z_write_through = true;    // (developer A/B: the serial frames' write-through intermediates may be used where the form exists)
     bool merged_x = true;           // ocean_set_merged_xpass: the one-launch x pass may be used where it applies (ocean_launch.h)
     uint32_t attr_n = 0;            // tile size whose kernels had their LDS attribute set through this context
     bool lambda_uniform = true;

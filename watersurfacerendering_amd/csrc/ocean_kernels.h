@@ -109,11 +109,11 @@ template <class T> __device__ __forceinline__ const T& at32(const T* base, unsig
 // the XCD's L2 as they are written instead of sitting there dirty until the end-of-kernel release writes everything back in one burst behind
 // the last workgroup; the x pass that reads them runs on whatever XCD its rows land on, so seven reads in eight come through the fabric anyway.
 // 2048^2 serial z pass 21.8-21.9 -> 20.4-20.7 us (x passes unchanged), 512^2 6.5-7.0 -> 6.2-6.6, 8 x 1024^2 36.9-37.2 -> 35.6-36.8; at 4096^2
-// -- several rounds of workgroups, 235 MB -- the same stores cost 6-8 us (90-95 -> 99-100), so up to 2048 only (z_write_through<N>()).
-#ifndef OCEAN_Z_WT_MAX
-#define OCEAN_Z_WT_MAX 2048
-#endif
-template <int N> constexpr bool z_write_through() { return N <= OCEAN_Z_WT_MAX; }
+// -- several rounds of workgroups, 235 MB -- the same stores cost 6-8 us (90-95 -> 99-100): not there.
+// A SERIAL frame only: pipelined 2048^2 frames lose 0.7 us per frame with it (47.4 -> 48.1 us, eight interleaved repeats: beside other
+// chains' launches the L2 is the better write buffer) -- so it is a store policy of its own, instantiated for the single-transform z pass at
+// the sizes where it pays (zpass_has_wt<N>()) and picked per launch (ocean_launch.h).
+template <int N> constexpr bool zpass_has_wt() { return N == 2048 || N == 1024; }
 template <bool ZNT, bool Z16 = false, bool WT = false> __device__ __forceinline__ void store_z(float2* base, unsigned idx, float2 v, float scale = 1.0f, float scale_y = 0.0f)
 {
     if constexpr (Z16) {
@@ -705,15 +705,15 @@ __device__ __forceinline__ void zpass_height_half(const FrameArgs& a, c32* fbuf,
             const int col = cols[c];
             c32 y0, y1;
             real_split(zx[t], zx[(M - t) & (M - 1)], wk[u], y0, y1);                         // k = t: rows t and M - t
-            store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, t), y0, su);
-            store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M - t), y1, su);
+            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, t), y0, su);
+            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M - t), y1, su);
             real_split(zx[M / 2 - t], zx[M / 2 + t], make_float2(wk[u].y, wk[u].x), y0, y1);  // k' = M/2 - t: rows M/2 - t and M/2 + t
-            store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M / 2 - t), y0, su);
-            if (t != 0) store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M / 2 + t), y1, su);
+            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 2 - t), y0, su);
+            if (t != 0) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 2 + t), y1, su);
             if (t == 0) {                                                                      // k = M/4: w^(N/8) = (1 + i) / sqrt 2
                 real_split(zx[M / 4], zx[3 * M / 4], make_float2(0.70710678118654752440f, 0.70710678118654752440f), y0, y1);
-                store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, M / 4), y0, su);
-                store_z<ZNT, Z16, z_write_through<N>()>(zh, HF::template zhidx<Z16>(col, 3 * M / 4), y1, su);
+                store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 4), y0, su);
+                store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, 3 * M / 4), y1, su);
             }
         }
     }
@@ -849,12 +849,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         auto out = [&](int p, int c, c32 v, int u, int i) {
             const unsigned pos = zo.pos(nb, p, u, i);
             if (c == 3) {
-                if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, pos, v, s3);
-                else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb, p, u, i), v, su);
+                if (jac) store_z<ZNT, Z16>(z3, pos, v, s3);
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);
                 return;
             }
             if (a.mode == 2) return;
-            store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
+            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
         };
         batch_fft<N, 4, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -880,7 +880,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
-            store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
+            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -917,12 +917,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, zo.pos(nb, p, u, i), v, s3);
+                if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
                 else if constexpr (zpass_half_height<N>()) return;                               // (the height follows below, as the other forms compute it)
-                else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
                 return;
             }
-            store_z<ZNT, Z16, z_write_through<N>()>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
+            store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<0>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, zo.pos(nb0 + c, p, u, i), v, su); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
                 float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
                 return zpass_input<1>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
+            auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
             batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         }
     }
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
             return zpass_input<2>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, false, 1.0f);
         };
-        auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
+        auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
     if constexpr (zpass_half_height<N>()) {
@@ -1063,8 +1063,8 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             return zpass_input<3>(kx, kx2, kzr[i], sv, sv, tz, tz, 1.0f, true, g3);
         };
         auto out = [&](int p, int c, c32 v, int u, int i) {
-            if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, zo.pos(nb0 + c, p, u, i), v, s3);
-            else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb0 + c, p, u, i), v, su);     // real input: other half is the conjugate
+            if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb0 + c, p, u, i), v, s3);
+            else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb0 + c, p, u, i), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void start_ramp_wait(int ramp, unsigned idx, unsigned
 // workgroups per CU, the same number of waves, and each one's load burst and store tail travel under the other's transforms.  Same radix
 // plan, same inputs (zpass_input), same twiddles: bit-identical to the other forms (tests/test_variants_gpu.py).
 // ============================================================================
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16>
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false>
 __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float (&kzr)[P::r[0]],
                                                         TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb)
 {
@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, zo.pos(nb, p, u, i), v, su); };
+            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, zo.pos(nb, p, u, i), v, su); };
             batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
-            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
+            auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
             batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
     }
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
         };
-        auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, z_write_through<N>()>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
+        auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
         batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
     if constexpr (zpass_half_height<N>()) {
@@ -1301,8 +1301,8 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return zpass_input<3>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, true, g3);
         };
         auto out = [&](int p, int, c32 v, int u, int i) {
-            if (jac) store_z<ZNT, Z16, z_write_through<N>()>(z3, zo.pos(nb, p, u, i), v, s3);
-            else if (zo.keeps(p, i)) store_z<ZNT, Z16, z_write_through<N>()>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
+            if (jac) store_z<ZNT, Z16, ZWT>(z3, zo.pos(nb, p, u, i), v, s3);
+            else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
         };
         batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
@@ -1312,7 +1312,7 @@ template <int N> constexpr size_t zpass_c1_lds_bytes() { return sizeof(c32) * ff
 
 // (the instantiations that carry all four forms of the spectrum -- !FAST: fp16 copy, fp32 dispersion -- need a few registers more than the
 //  80 of six waves per SIMD and spilled 24-28 bytes per lane under that cap: they ask for five, 96 registers, no scratch)
-template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true>
+template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true, bool ZWT = false>
 __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1366,8 +1366,9 @@ __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs 
     for (int i = 0; i < P::r[0]; ++i) kzr[i] = k1[tid + i * (N / P::r[0])];
     __syncthreads();
     const float sm0 = raw[0];
-    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
-    else zpass_single_transforms<N, T, P, false, ZNT, Z16>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+    static_assert(!ZWT || (!ZNT && !Z16), "write-through is a policy of the plain fp32 intermediates");
+    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_single_transforms<N, T, P, false, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
 }
 // tile sizes whose z pass has the single-transform form (the launcher picks it where it is faster: ocean_launch.h)
 template <int N> constexpr bool zpass_has_c1() { return N >= 1024; }

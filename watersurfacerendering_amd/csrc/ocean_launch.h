@@ -84,7 +84,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #define OCEAN_ALLOW_Z(znt, z16, fast) \
         if constexpr (HAS1) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, lds_rows)) != hipSuccess) return e; \
         if constexpr (HAS2 && (znt || HAS2_PLAIN)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, lds_rows2)) != hipSuccess) return e; \
-        if constexpr (HASC1) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e;
+        if constexpr (HASC1) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e; \
+        if constexpr (HASC1 && zpass_has_wt<N>() && !znt && !z16) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, fast, true>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e;
 #define OCEAN_ALLOW_Z2(fast) OCEAN_ALLOW_Z(false, false, fast) OCEAN_ALLOW_Z(true, false, fast) OCEAN_ALLOW_Z(false, true, fast) OCEAN_ALLOW_Z(true, true, fast)
         OCEAN_ALLOW_Z2(true) OCEAN_ALLOW_Z2(false)
 #undef OCEAN_ALLOW_Z2
@@ -181,8 +182,17 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         }
         hipEvent_t* mz = next_marks(0);
         bool launched = false;
+        // a SERIAL frame's fp32 intermediates go out write-through where that form exists (ocean_kernels.h: store_z, zpass_has_wt)
+        if constexpr (HASC1 && zpass_has_wt<N>()) {
+            if (c1 && alone && !(stream_maps & (4 | 8)) && c->z_write_through) {
+                if (fast) launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, true, true>, grid, block, lds, st, mz, za);
+                else launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, false, true>, grid, block, lds, st, mz, za);
+                launched = true;
+                if (launches == 1) c->last_launch[0].flags |= OCEAN_LAUNCH_WT_INTER;
+            }
+        }
 #define OCEAN_ZPASS3(znt, z16, fast) \
-        do { if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
+        do { if (launched) break; if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
              if constexpr (HAS2 && (znt || HAS2_PLAIN)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
              if constexpr (HAS1) { if (!c1 && !zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds, st, mz, za); launched = true; } } } while (0)
 #define OCEAN_ZPASS2(znt, z16) \
