@@ -253,34 +253,47 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The roofline fractions of the committed default bench line (profiles/r04n_bench_default.json) can be recomputed from
-    the committed rocprofv3 summary (profiles/kernel_stats.json <- r04n_kernel_stats_2048_bench_depth1.csv) and the byte
-    accounting of this file: every kernel within 8 % (two processes: the hardware queue a context's stream lands on moves a kernel by up
-    to +-1 us, profiles/r03_bimodal_probe.txt section 4a -- 6 % of the 17 us displacement pass), nothing above 1, and the summaries
-    regenerate from the CSV."""
+    """The committed default bench run (profiles/r05n_bench_default.json = the compact stdout line, profiles/r05n_bench_extra_default.json = its
+    sidecar) against the committed rocprofv3 summary (profiles/kernel_stats.json <- r05n_kernel_stats_2048_bench_depth1.csv) and the byte
+    accounting of this file: every kernel's fraction within 8 % of the one recomputed from the rocprofv3 average (two processes on two boxes: the
+    hardware queue a context's stream lands on moves a kernel by up to +-1 us, profiles/r03_bimodal_probe.txt section 4a), nothing above 1, the
+    line below the size limit, and the summaries regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    line = [l for l in open(os.path.join(prof, "r04n_bench_default.json")).read().splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    raw = open(os.path.join(prof, "r05n_bench_default.json")).read()
+    lines = [l for l in raw.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_BYTES_MAX
+    d = json.loads(lines[0])
+    side = json.load(open(os.path.join(prof, "r05n_bench_extra_default.json")))
+    assert side["line"] == d
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
     n2 = 2048 * 2048
     assert d["config"]["tile_size"] == 2048 and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert r["profiles_current"] is True and r["traffic"] is not None and r["rocprof_launch_us"] is not None     # measured with the committed kernels
     for k, b in bench.KERNEL_BYTES_ACTUAL.items():
         frac_from_rocprof = b * n2 / (st[k + "@2048"]["avg_us"] * 1e-6) * 1e-9 / bench.HBM_PEAK_GBPS
         assert abs(r["kernels"][k]["frac"] - frac_from_rocprof) <= 0.08 * frac_from_rocprof, (k, r["kernels"][k]["frac"], frac_from_rocprof)
-        assert r["kernels"][k]["frac"] < 1.0
+        assert r["kernels"][k]["frac"] < 1.0 and r["kernels"][k]["bytes_per_texel"] == b
     assert r["frac"] == r["kernels"][r["kernel"]]["frac"] and r["frame_frac"] < 1.0 and r["serial_frame_frac"] < 1.0
-    assert abs(r["frame_frac"] - bench.FRAME_BYTES_ACTUAL * n2 / (d["ms_per_step"] * 1e-3) * 1e-9 / bench.HBM_PEAK_GBPS) < 1e-9
-    # round 4: the timed region is repeated and reported as median with spread; the CPU baseline names the usable cores
+    assert r["rocprof_frac"] == pytest.approx(bench.KERNEL_BYTES_ACTUAL[r["kernel"]] * n2 / (r["rocprof_launch_us"] * 1e-6) * 1e-9 / bench.HBM_PEAK_GBPS, rel=1e-4)
+    assert abs(r["frame_frac"] - bench.FRAME_BYTES_ACTUAL * n2 / (d["ms_per_step"] * 1e-3) * 1e-9 / bench.HBM_PEAK_GBPS) < 1e-5
+    assert 0.85 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.15 * r["algorithmic_bytes_per_launch"]           # no wasted re-reads
+    # the timed region is repeated and reported as median with spread; the CPU baseline names the usable cores
     assert d["timing"]["regions"] >= 7 and d["timing"]["ms_per_step_p10"] <= d["ms_per_step"] <= d["timing"]["ms_per_step_p90"]
-    assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["nproc"] and d["cpu_baseline"]["cores"] == d["cpu_baseline"]["host"]["usable_cpus"]
-    assert {"4096x4096_fp32_depth3", "4096x4096_fp16_spectrum_depth3", "4096x4096_fp16_intermediates_depth3"} <= set(d["extra"])
-    assert d["extra"]["4096x4096_fp32_depth3"]["error_vs_float64_oracle"] <= 1e-5 < d["extra"]["4096x4096_fp16_spectrum_depth3"]["error_vs_float64_oracle"] <= 1e-3
+    assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["nproc"] and d["cpu_baseline"]["cores"] == side["cpu_baseline"]["host"]["usable_cpus"]
+    ex = side["extra"]
+    assert {"4096x4096_fp32_depth3", "4096x4096_fp16_spectrum_depth3", "4096x4096_fp16_intermediates_depth3"} <= set(ex)
+    assert ex["4096x4096_fp32_depth3"]["error_vs_float64_oracle"] <= 1e-5 < ex["4096x4096_fp16_spectrum_depth3"]["error_vs_float64_oracle"] <= 1e-3
+    sc = ex["2048x2048_synchronous_calls"]
+    assert sc["calls"] >= 1000 and sc["pinned_thread_gc_off"]["p95_over_median"] <= 1.15
+    # the driver's invocation, committed beside it: parsed line, the same keys
+    short = json.loads([l for l in open(os.path.join(prof, "r05n_bench_steps20_warmup5.json")).read().splitlines() if l.startswith("{")][-1])
+    assert short["steps"] == 20 and short["warmup"] == 5 and set(short) == set(d) and short["roofline"]["frac"] < 1.0
     # the summary itself regenerates from the committed CSV
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r04n_kernel_stats_2048_bench_depth1.csv"))):
+    for row in csv.DictReader(open(os.path.join(prof, "r05n_kernel_stats_2048_bench_depth1.csv"))):
         m = re.search(r"(k_[a-z_0-9]+)<2048", row["Name"])
         name = m.group(1) if m else None
         if name and name.startswith("k_zpass"):          # the z pass's kernel forms (k_zpass, k_zpass_c1) are all the frame's first launch

@@ -6,6 +6,7 @@
 if [ "$1" = "--collect" ]; then
   T=$2; cd "$(dirname "$0")/.." || exit 1
   for f in 2048_bench_depth1 2048_bench_depth3 512x1_serial 4096x1_serial 1024x8_serial; do cp gpurun_out/${T}_kernel_stats_$f.csv profiles/; done
+  for f in bench_default bench_extra_default bench_steps20_warmup5 bench_extra_steps20_warmup5; do cp gpurun_out/${T}_$f.json profiles/; done
   cp gpurun_out/pmc_${T}_2048_summary.txt profiles/${T}_pmc_2048_single_tile.txt
   cp gpurun_out/pmc_${T}_4096_summary.txt profiles/${T}_pmc_4096_single_tile.txt
   cp gpurun_out/pmc_${T}_1024x8_summary.txt profiles/${T}_pmc_1024_batch8.txt
@@ -31,4 +32,5 @@ bash tools/pmc_depth.sh ${T}_2048_d3 2048 60 1 3 > /dev/null
 bash tools/pmc_depth.sh ${T}_4096_d3 4096 30 1 3 > /dev/null
 cd $GRAFT_REPO_ROOT && python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_steps20_warmup5.json 2> gpurun_out/${T}_bench_steps20_warmup5.err
 echo steps20 rc=$?
+cp bench_extra.json gpurun_out/${T}_bench_extra_steps20_warmup5.json
 ls gpurun_out | grep $T | head -40

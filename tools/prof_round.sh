@@ -18,3 +18,4 @@ done
 rocprofv3 -L 2>/dev/null | grep -i -B1 -A4 "RDREQ\|WRREQ" > $R/gpurun_out/${TAG}_counters_rdreq.txt
 cd $R && python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 echo bench rc=$?
+cp bench_extra.json gpurun_out/${TAG}_bench_extra_default.json      # the sidecar of that run (everything beside the compact stdout line)
