@@ -829,13 +829,22 @@ def main():
     # serial frames of the bench context are reported beside it (roofline.serial_kernels_in_bench_context_us).  The hardware queue a
     # context's stream lands on moves these figures by +-1 us per kernel between passes (profiles/r03_bimodal_probe.txt 4a); the slow
     # k_xpass_b of earlier rounds (one process in 4...25) is gone since its victim workgroup is dispatched first (profiles/r03_xpass_trace.txt).
-    bs = W.OceanBatch(n, tiles, local_rank)
-    bs.prepare(SEED + first_tile)
-    ms_serial, kern_ms = bs.time_frames(0.0, DT, 300, nk, per_kernel=True)
-    serial_us_per_step = ms_serial / nk * 1e3
-    bs.close()
+    # THREE such contexts, one after the other, and the one with the median frame time is reported (all three are in the sidecar): about
+    # one context in ten runs its z pass 20-25 % slower than the others of the same process for as long as it lives (seen on fresh boxes and
+    # right behind counter-collection runs; not the clocks -- tools/clock_ramp.py --, not the code -- tools/ctx_spread.py: fourteen contexts,
+    # one value), and a single pass would report whichever it drew.
+    passes = []
+    for _ in range(3):
+        bs = W.OceanBatch(n, tiles, local_rank)
+        bs.prepare(SEED + first_tile)
+        ms_serial_i, kern_ms_i = bs.time_frames(0.0, DT, 300, nk, per_kernel=True)
+        bs.close()
+        passes.append((ms_serial_i / nk * 1e3, kern_ms_i))
+    serial_us_per_step, kern_ms = sorted(passes, key=lambda p: p[0])[1]
     roofline = roofline_object(n, tiles, names, kern_ms, kern_ms_pipe, args.depth, ms_per_step, serial_us_per_step, own_bpt, kernel_bytes)
-    roofline["serial_pass"] = "a context of its own at pipeline depth 1 (the synchronous-call configuration), 300 warm-up + 200 timed frames"
+    roofline["serial_pass"] = ("contexts of their own at pipeline depth 1 (the synchronous-call configuration), 300 warm-up + 200 timed frames each; "
+                               "three of them, the one with the median frame time is reported")
+    roofline["serial_passes_us"] = [{"frame": p[0], **{k: v * 1e3 for k, v in zip(names, p[1])}} for p in passes]
     if kern_ms_main is not None:
         roofline["serial_kernels_in_bench_context_us"] = {k: v * 1e3 for k, v in zip(names, kern_ms_main)}
 

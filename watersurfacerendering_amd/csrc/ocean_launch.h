@@ -184,7 +184,11 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         bool launched = false;
         // a SERIAL frame's fp32 intermediates go out write-through where that form exists (ocean_kernels.h: store_z, zpass_has_wt)
         if constexpr (HASC1 && zpass_has_wt<N>()) {
-            if (c1 && alone && !(stream_maps & (4 | 8)) && c->z_write_through) {
+            bool wt = c1 && alone && !(stream_maps & (4 | 8)) && c->z_write_through;
+#ifdef OCEAN_DEVELOPER
+            if (const char* ev = getenv("OCEAN_Z_WT")) wt = wt && atoi(ev) != 0;     // (read per frame: A/B inside one process)
+#endif
+            if (wt) {
                 if (fast) launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, true, true>, grid, block, lds, st, mz, za);
                 else launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, false, true>, grid, block, lds, st, mz, za);
                 launched = true;
