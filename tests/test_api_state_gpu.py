@@ -478,3 +478,53 @@ def test_stream_selection_orders_the_queues_and_changes_no_bit():
     ref.compute_waves(2.5)
     assert np.array_equal(b.read_maps()[0], ref.read_maps()[0])
     b.close(); ref.close()
+
+
+def test_round5_switches_change_launches_and_no_bit():
+    """The switches round 5 added for what the library otherwise decides (include/ocean.h): ocean_set_start_ramp(0)
+    takes the staggered start off a 2048^2 frame's launches, ocean_set_merged_xpass(0) gives pipelined small tiles their three launches back,
+    ocean_set_external_readers(0 / 1) moves the synchronous call between the completion-record poll and the stream synchronisation after
+    ocean_device_maps -- and none of them changes a bit of a frame; ocean_build_id() is the hash of the sources beside the library."""
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi as A
+    assert A.lib().ocean_build_id().decode() == A.source_build_id() == A.library_build_id()
+    # staggered start
+    n = 2048
+    out = []
+    for on in (True, False):
+        b = W.OceanBatch(n, 1, 0)
+        b.set_start_ramp(on)
+        b.prepare(SEED + 11)
+        amp = b.compute_waves(0.9)
+        flags = [li["flags"] for li in b.last_launch()]
+        assert all(bool(f & A.OCEAN_LAUNCH_STAGGERED_START) == on for f in flags), (on, flags)
+        assert bool(flags[0] & A.OCEAN_LAUNCH_WT_INTER)                   # (a serial 2048^2 frame: write-through intermediates either way)
+        out.append((amp, *b.read_maps()))
+        b.close()
+    assert all(np.array_equal(x, y) for x, y in zip(out[0], out[1]))
+    # merged x pass: pipelined 512^2 frames, on / off
+    n = 512
+    out = []
+    for on in (True, False):
+        b = W.OceanBatch(n, 1, 0)
+        b.set_merged_xpass(on); b.set_pipeline_depth(3)
+        b.prepare(SEED + 12)
+        for j in range(5):
+            b.compute_waves_async(0.2 * j)
+        b.synchronize()
+        assert all(bool(li["flags"] & A.OCEAN_LAUNCH_MERGED_X) == on for li in b.last_launch()[1:])
+        out.append(b.read_maps())
+        b.close()
+    assert all(np.array_equal(x, y) for x, y in zip(out[0], out[1]))
+    # external readers: the flag ocean_device_maps sets can be taken back (and set by hand); frames and amplitudes are the same in both wait modes
+    b = W.OceanBatch(256, 1, 0)
+    b.prepare(SEED + 13)
+    a0 = b.compute_waves(0.3)
+    b.device_maps()                                      # -> the synchronous call synchronises the stream from here on
+    a1 = b.compute_waves(0.3)
+    b.set_external_readers(False)                        # every consumer is on ocean_stream(): back to the poll
+    a2 = b.compute_waves(0.3)
+    b.set_external_readers(True)
+    a3 = b.compute_waves(0.3)
+    assert np.array_equal(a0, a1) and np.array_equal(a0, a2) and np.array_equal(a0, a3)
+    b.close()
