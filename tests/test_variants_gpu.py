@@ -173,6 +173,15 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
             # nor is the merged x pass (round 5): k_xpass_b's instantiation with its DISP workgroups in the same launch -- single small tiles, not the Jacobian mode
             merged = A.OCEAN_LAUNCH_MERGED_X
             assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= (128 if depth == 1 else 512) and tiles == 1 and not jac), what
+            # ... and the whole frame as ONE launch (k_frame: the bodies of k_zpass and k_xpass_b in one grid): pipelined frames of one tile up to
+            # 512^2 in the usual form (fp32 spectrum, 16-bit dispersion, fp32 intermediates)
+            one = A.OCEAN_LAUNCH_ONE_LAUNCH
+            want_one = n <= 512 and tiles == 1 and depth > 1 and not (jac or z16 or h16 or w32)
+            assert all(bool(li["flags"] & one) == want_one for li in (z, xb, xd)), what
+            if want_one:        # (its launch record carries no store-policy flags of the z pass: mapped onto the three-launch variant it replaces)
+                assert z["grid_x"] == xb["grid_x"] == xd["grid_x"] and xb["flags"] & A.OCEAN_LAUNCH_NT_MAPS, what
+                z = dict(z, flags=z["flags"] & ~one)
+                xb = dict(xb, flags=xb["flags"] & ~one); xd = dict(xd, flags=xd["flags"] & ~one)
             if xb["flags"] & merged:
                 assert xb["grid_x"] == xd["grid_x"] and (xb["flags"] & ~A.OCEAN_LAUNCH_NT_MAPS) == (xd["flags"] & ~A.OCEAN_LAUNCH_NT_MAPS), what
             assert not any(li["flags"] & A.OCEAN_LAUNCH_SPLIT_ORDER for li in (z, xb, xd)), what      # (developer builds only: profiles/r05_4096_experiments.txt)
@@ -299,6 +308,8 @@ def test_merged_x_pass_delivers_the_bits_of_the_three_launch_frame(n, oracles):
         d1, q1, h1, a1, l1 = frames(False, mode, bits, depth, sync)
         d2, q2, h2, a2, l2 = frames(True, mode, bits, depth, sync)
         assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l1), what
+        # pipelined frames in the usual form go one step further: the whole frame as ONE launch (k_frame)
+        assert all(bool(li["flags"] & A.OCEAN_LAUNCH_ONE_LAUNCH) == (depth > 1 and bits == 32) for li in l2), what
         if n > 128 and depth == 1:          # serial frames from 256^2 up keep three launches (the hand-off costs more than the boundary it replaces)
             assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l2), what
         else:

@@ -48,6 +48,7 @@ OCEAN_LAUNCH_STAGGERED_START = 256
 OCEAN_LAUNCH_SPLIT_ORDER = 512      # developer builds only
 OCEAN_LAUNCH_MERGED_X = 1024
 OCEAN_LAUNCH_WT_INTER = 2048
+OCEAN_LAUNCH_ONE_LAUNCH = 4096
 
 
 class OceanError(RuntimeError):

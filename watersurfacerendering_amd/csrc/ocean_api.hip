@@ -52,12 +52,12 @@ static void free_device(ocean_ctx* c)
 
 static void free_set(ocean_ctx* c, int i)
 {
-    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->z3[i], c->jraw[i], c->jac0[i], c->minmax[i], c->hdone[i], c->done_ctr[i], c->dispN[i]};   // (nrmN: same allocation)
+    void* per[] = {c->z[i], c->zh[i], c->hraw[i], c->z3[i], c->jraw[i], c->jac0[i], c->minmax[i], c->hdone[i], c->zdone[i], c->done_ctr[i], c->dispN[i]};   // (nrmN: same allocation)
     for (void* b : per) if (b) (void)hipFree(b);
     if (c->done_rec[i]) (void)hipHostFree(c->done_rec[i]);
     for (auto& p : c->pack_half[i]) if (p) { (void)hipFree(p); p = nullptr; }
     c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->z3[i] = nullptr; c->jraw[i] = nullptr; c->jac0[i] = nullptr;
-    c->minmax[i] = nullptr; c->hdone[i] = nullptr; c->done_ctr[i] = nullptr; c->done_rec[i] = nullptr; c->seq[i] = 0;
+    c->minmax[i] = nullptr; c->hdone[i] = nullptr; c->zdone[i] = nullptr; c->zgen[i] = 0; c->done_ctr[i] = nullptr; c->done_rec[i] = nullptr; c->seq[i] = 0;
     c->dispN[i] = nullptr; c->nrmN[i] = nullptr;
 }
 
@@ -76,6 +76,9 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     HIP_TRY(hipMemsetAsync(c->hraw[i], 0, t * nup * n * sizeof(float), stream_of(c, i)));
     HIP_TRY(hipMalloc(&c->minmax[i], t * 2 * sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->hdone[i], t * sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&c->zdone[i], t * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(c->zdone[i], 0, t * sizeof(unsigned), stream_of(c, i)));
+    c->zgen[i] = 0;
     HIP_TRY(hipMalloc(&c->done_ctr[i], (1 + DONE_GROUPS) * DONE_STRIDE * sizeof(unsigned)));
     HIP_TRY(hipMemsetAsync(c->done_ctr[i], 0, (1 + DONE_GROUPS) * DONE_STRIDE * sizeof(unsigned), stream_of(c, i)));
     // the last workgroup of a frame drops (min key, max key, sequence number) per tile into this host-coherent
@@ -484,6 +487,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set]; a.hdone = c->hdone[set];
+    a.zdone = c->zdone[set]; a.zdone_target = 0; c->cur_set = set;
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
     a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
     // the chain's sequence number, tracking and burst state are committed only once the launches have succeeded; a failed enqueue
@@ -571,6 +575,8 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         g_last_hip = (int)e;
         c->seq[set] = 0;
         if (c->last_set == set) c->have_frame = false;
+        c->zgen[set] = 0;                                   // (a one-launch frame may have counted itself without running: start over)
+        (void)hipMemsetAsync(c->zdone[set], 0, c->tiles * sizeof(unsigned), st);
         return OCEAN_E_HIP;
     }
     if (pipe) {

@@ -56,6 +56,10 @@ struct ocean_ctx {
     float* jraw[MAXD] = {};        // allocated by a chain's first frame of that mode (alloc_jacobian), never by the others
     float* jac0[MAXD] = {};
     unsigned* minmax[MAXD] = {};
+    unsigned* zdone[MAXD] = {};     // [tiles] z-pass workgroups that have finished, counted up for ever (one-launch frames: FrameArgs::zdone)
+    unsigned zgen[MAXD] = {};       // one-launch frames the chain has run (zdone's target = zgen x (N/2 + 1))
+    int cur_set = 0;                // the chain of the frame being enqueued (for the launcher)
+    uint32_t attr_one_n = 0;        // tile size whose one-launch kernel had its LDS attribute set through this context
     unsigned* hdone[MAXD] = {};     // [tiles] HEIGHT workgroups of the chain's current frame that have finished (merged x pass: FrameArgs::hdone)
     uint4* done_rec[MAXD] = {};     // [tiles] host-coherent completion records (min key, max key, sequence, 0) written by the last
                                     //   workgroup of a frame's last kernel (ocean_kernels.h: frame_done)

@@ -192,6 +192,9 @@ struct FrameArgs {
     float* jraw;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: signed d(Dx)/dz = d(Dz)/dx of the same rows
     float* jac0;             // [tiles][NUP][N]          OCEAN_MODE_JACOBIAN: (1 + lambda dDx/dx)(1 + lambda dDz/dz) of the same rows
     unsigned* minmax;        // [tiles][2]       ordered-int keys of min, max
+    unsigned* zdone;         // [tiles]          z-pass workgroups that have finished, counted up frame after frame (never reset): what the x-axis
+                             //                  workgroups of a ONE-LAUNCH frame (k_frame) wait for -- until it has reached zdone_target
+    unsigned zdone_target;   //                  (N/2 + 1) x the number of one-launch frames this chain has run, this one included (mod 2^32)
     unsigned* hdone;         // [tiles]          HEIGHT workgroups of the frame that have finished (reset by the z pass): what the DISP workgroups
                              //                  of a merged x pass wait for (k_xpass_b, xb_roles bit 2)
     uint4* done_rec;         // [tiles]          host-coherent completion records (min key, max key, frame_seq, 0), written by the
@@ -791,7 +794,7 @@ __device__ __forceinline__ c32 zpass_input(float kx, float kx2, float kz, float 
     else return make_float2(sv, jac ? g3 * (kx * kz * inv * tc) : 0.0f);
 }
 
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC>
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, int ZC, bool ZWT = false>
 __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float* kzt,
                                                  TwiddleRegs<N, ZC, T, P>& twr, float kx, float sm0, int tid,
                                                  int tile, int nb, int batches /* bit 0: {pair 0, pair 1}, bit 1: {pair 2, height} */)
@@ -849,12 +852,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         auto out = [&](int p, int c, c32 v, int u, int i) {
             const unsigned pos = zo.pos(nb, p, u, i);
             if (c == 3) {
-                if (jac) store_z<ZNT, Z16>(z3, pos, v, s3);
-                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);
+                if (jac) store_z<ZNT, Z16, ZWT>(z3, pos, v, s3);
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);
                 return;
             }
             if (a.mode == 2) return;
-            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
+            store_z<ZNT, Z16, ZWT>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + pos, v, c == 0 ? su : sk);
         };
         batch_fft<N, 4, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -880,7 +883,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
 #ifdef OCEAN_ABL_NOSTORE
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
-            store_z<ZNT, Z16>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
+            store_z<ZNT, Z16, ZWT>(zt, (unsigned)c * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, c ? sk : su);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(2);
@@ -917,12 +920,12 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
             asm volatile("" ::"v"(v.x), "v"(v.y)); if (p >= 0) return;
 #endif
             if (c) {
-                if (jac) store_z<ZNT, Z16>(z3, zo.pos(nb, p, u, i), v, s3);
+                if (jac) store_z<ZNT, Z16, ZWT>(z3, zo.pos(nb, p, u, i), v, s3);
                 else if constexpr (zpass_half_height<N>()) return;                               // (the height follows below, as the other forms compute it)
-                else if (zo.keeps(p, i)) store_z<ZNT, Z16>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
+                else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
                 return;
             }
-            store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
+            store_z<ZNT, Z16, ZWT>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk);
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
@@ -1091,10 +1094,12 @@ template <int N> constexpr int zpass_min_waves() { return N == 2048 ? 6 : (N >= 
 #ifndef OCEAN_ZLB
 #define OCEAN_ZLB zpass_min_waves<N>()
 #endif
-template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true>
-__global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
+// The body of k_zpass as a device function: k_frame (the one-launch frame of pipelined small tiles) runs it for its first N/2 + 1 workgroups.
+// bx / gx: the workgroup's index and count among the z-pass workgroups of its tile; ONE: part of a one-launch frame -- the intermediates go out
+// write-through and the per-tile words the x-axis workgroups of the SAME launch update by atomics are reset write-through too.
+template <int N, int T, class P, bool ZNT, bool Z16, int ZW, bool FAST, bool ONE = false>
+__device__ __forceinline__ void zpass_body(const FrameArgs& a, unsigned char* smem, const int bx, const int gx)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ZC = zpass_columns<N>();
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // ZC interleaved transforms
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, ZC>());   // S+ [N]
@@ -1151,25 +1156,31 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
             }
         }
     });
-    if (blockIdx.x == 0 && tid == 0 && (a.zmask & 8)) {   // (the launch that transforms the height: ahead of the HEIGHT workgroups' atomics)
+    if (bx == 0 && tid == 0 && (a.zmask & 8)) {   // (the launch that transforms the height: ahead of the HEIGHT workgroups' atomics)
         // min starts at FLT_MAX, max at FLT_MIN (> 0): WSTessendorf.cpp:289-290
-        a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
-        a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
-        a.hdone[tile] = 0u;                                   // (merged x pass: its DISP workgroups count the HEIGHT workgroups up from here)
+        if constexpr (ONE) {        // the atomics of this very launch's HEIGHT workgroups follow (behind zdone): the resets must not sit in this XCD's L2
+            __hip_atomic_store(a.minmax + 2 * tile + 0, float_key(3.402823466e+38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.minmax + 2 * tile + 1, float_key(1.175494351e-38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.hdone + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            a.minmax[2 * tile + 0] = float_key(3.402823466e+38f);
+            a.minmax[2 * tile + 1] = float_key(1.175494351e-38f);
+            a.hdone[tile] = 0u;                                   // (merged x pass: its DISP workgroups count the HEIGHT workgroups up from here)
+        }
     }
     __syncthreads();
     const float sm0 = raw[0];
     OCEAN_STAMP(1);
 
-    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
-    else zpass_transforms<N, T, P, false, ZNT, Z16, ZC>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
+    if (col0) zpass_transforms<N, T, P, true, ZNT, Z16, ZC, ONE>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
+    else zpass_transforms<N, T, P, false, ZNT, Z16, ZC, ONE>(a, fbuf, sp, kzt, twr, k1[nb], sm0, tid, tile, nb, batches);
     };
 
     if constexpr (ZW == 2) {
         // N/4 + 1 workgroups: block 0 = the Nyquist column 0 and column 1 one after the other, blocks 1 .. N/4-1 = columns
         // 2b, 2b+1 together, the last one = column N/2 alone (dispatched last: the shortest job closes the grid)
         constexpr int LAST = N / 4;
-        const int blk = (int)blockIdx.x == LAST ? LAST : xcd_swizzle((int)blockIdx.x, LAST);
+        const int blk = bx == LAST ? LAST : xcd_swizzle(bx, LAST);
         if (blk != 0 && blk != LAST) {
             zpass_two_columns<N, T, P, ZNT, Z16, FAST>(a, smem, twr, tid, tile, 2 * blk);
             return;
@@ -1179,13 +1190,20 @@ __global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
         __syncthreads();            // the slowest wave is done with the FFT image before the next column's h~ overwrites it
         one_column(1, 3);
     } else {
-        int nb = (int)blockIdx.x;
+        int nb = bx;
         const int batches = 3;
 #if OCEAN_ZTILE
-        nb = xcd_swizzle(nb, (int)gridDim.x);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
+        nb = xcd_swizzle(nb, gx);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
 #endif
         one_column(nb, batches);
     }
+}
+
+template <int N, int T, class P = Plan<N>, bool ZNT = false, bool Z16 = false, int ZW = 1, bool FAST = true>
+__global__ void __launch_bounds__(T, OCEAN_ZLB) k_zpass(const FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    zpass_body<N, T, P, ZNT, Z16, ZW, FAST>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // A launch whose workgroups are all resident at once on an otherwise idle device reads everything, then writes everything: the first quarter of
@@ -1422,6 +1440,16 @@ __device__ __forceinline__ void wait_counter(const unsigned* ctr, unsigned targe
     __syncthreads();
 }
 
+// the same for a counter that is never reset: until it has REACHED target (mod 2^32: the frames of a chain count it up for ever)
+__device__ __forceinline__ void wait_counter_reached(const unsigned* ctr, unsigned target, int tid)
+{
+    if (tid == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(load_wt(ctr) - target) < 0 && (wall_clock64() - t0) < 2000000ull) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+}
+
 // ---- x-pass helpers ------------------------------------------------------------------
 // Column u of a packed pair: rows 0..N/2 come from side 0; row mf > N/2 is the
 // mirror image eps * Z(N-mf, N-u) = eps * side 1 of row N-mf.
@@ -1508,13 +1536,14 @@ template <int N, int C> constexpr int xpass_height_groups() { return (N / 2 + 1 
 // the workgroups of a round finish together and a single word takes ~88 atomics per microsecond (257 of them: +2 us on the 2048^2
 // displacement pass; two-level: see DESIGN.md section 6).
 constexpr unsigned DONE_GROUPS = 1024, DONE_STRIDE = 16;      // counter g at done_ctr[(1 + g) * DONE_STRIDE], the top one at [0]
+// (total / id: the workgroups that count and this one's index among them -- the whole grid by default; k_frame's z-pass workgroups do not count)
 template <int T>
-__device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_flag, int tid)
+__device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_flag, int tid, unsigned total = 0, unsigned id = 0)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's map stores have been taken
     __syncthreads();                                        // ... every wave's; nobody reads the FFT image any more
     if (tid == 0) {
-        const unsigned total = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        if (total == 0) { total = gridDim.x * gridDim.y; id = blockIdx.y * gridDim.x + blockIdx.x; }
         const unsigned groups = total / 16u < DONE_GROUPS ? (total + 15u) / 16u : DONE_GROUPS;
         const unsigned g = id % groups, members = total / groups + (g < total % groups ? 1u : 0u);
         unsigned* gc = a.done_ctr + (1u + g) * DONE_STRIDE;
@@ -1529,26 +1558,30 @@ __device__ __forceinline__ void frame_done(const FrameArgs& a, unsigned* lds_fla
     if (!lds_flag[0]) return;
     if (tid == 0) *a.done_ctr = 0u;                         // for the chain's next frame (stream order)
     for (unsigned i = (unsigned)tid; i < gridDim.y; i += (unsigned)T)
-        a.done_rec[i] = make_uint4(a.minmax[2 * i + 0], a.minmax[2 * i + 1], a.frame_seq, 0u);     // one 16-byte store
+        a.done_rec[i] = make_uint4(load_wt(a.minmax + 2 * i + 0), load_wt(a.minmax + 2 * i + 1), a.frame_seq, 0u);     // one 16-byte store (the keys past the
+                                                                                        // L1 / this XCD's L2: in a merged launch this very launch's atomics wrote them)
 }
 
 
 // The records of a launch (FrameArgs::rec_mode): the early form by the first workgroup of each tile (the height keys are final when the
 // frame's last launches run), or the counted form.  Called by every thread of every workgroup of the launch, behind its work.
 template <int T>
-__device__ __forceinline__ void frame_records(const FrameArgs& a, unsigned* lds_flag, int tid, bool first_of_tile)
+__device__ __forceinline__ void frame_records(const FrameArgs& a, unsigned* lds_flag, int tid, bool first_of_tile, unsigned total = 0, unsigned id = 0)
 {
     if (a.rec_mode == 1) {
-        if (first_of_tile && tid == 0) a.done_rec[blockIdx.y] = make_uint4(a.minmax[2 * blockIdx.y + 0], a.minmax[2 * blockIdx.y + 1], a.frame_seq, 0u);
+        if (first_of_tile && tid == 0) a.done_rec[blockIdx.y] = make_uint4(load_wt(a.minmax + 2 * blockIdx.y + 0), load_wt(a.minmax + 2 * blockIdx.y + 1), a.frame_seq, 0u);
     } else if (a.rec_mode == 2) {
-        frame_done<T>(a, lds_flag, tid);
+        frame_done<T>(a, lds_flag, tid, total, id);
     }
 }
 
-template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
-__global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
+// The body of k_xpass_b as a device function (k_frame runs it for the workgroups behind its z-pass ones).  bx_in: the workgroup's index among
+// the launch's x-axis workgroups; ONE: part of a one-launch frame -- all three roles (HEIGHT, NORMAL, DISP), every workgroup first waits until
+// the tile's z-pass workgroups of the same launch have counted themselves in (FrameArgs::zdone; they are dispatched first and wait for nobody),
+// and the records' workgroup count leaves the z-pass workgroups out (rec_total / rec_id).
+template <int N, int C, int T, class P, bool NTS, bool Z16, bool JAC, bool ONE = false>
+__device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* smem, const int bx_in, const unsigned rec_total = 0, const unsigned rec_id = 0)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using HF = Half<N>;
     c32* fbuf = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -1563,7 +1596,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     constexpr int HB = JAC ? NB : xpass_height_groups<N, C>();      // height workgroups
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     // a launch holds the HEIGHT workgroups, the NORMAL workgroups or (usually) both: a.xb_roles; bx = the index in the full grid
-    const int bx = (int)blockIdx.x + (a.xb_roles == 2 ? HB : 0);
+    const int bx = bx_in + (a.xb_roles == 2 ? HB : 0);
+    if constexpr (ONE) wait_counter_reached(a.zdone + tile, a.zdone_target, tid);      // the intermediates of THIS frame are all written (write-through)
 
     // (the roles are lambdas: every workgroup of a launch, whatever its role, ends in frame_records)
     auto pair3_role = [&]() {
@@ -1849,7 +1883,42 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
     else normal_role();
     // the launch's records: the early form needs the final height keys -- the first NORMAL workgroup of a launch behind the HEIGHT
     // workgroups' launch (split order), the first DISP workgroup of a merged launch (it has waited for them)
-    frame_records<T>(a, reinterpret_cast<unsigned*>(smem), tid, merged_launch ? bx == HB + NB : bx == HB);
+    frame_records<T>(a, reinterpret_cast<unsigned*>(smem), tid, merged_launch ? bx == HB + NB : bx == HB, rec_total, rec_id);
+}
+
+template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>
+__global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    xpass_b_body<N, C, T, P, NTS, Z16, JAC>(a, smem, (int)blockIdx.x);
+}
+
+// ============================================================================
+// k_frame: a whole frame in ONE launch (round 5) -- for PIPELINED frames of one small tile, which are bound by the rate at which launches get
+// through the process's hardware queues (profiles/r05_small_tile_experiments.txt).  Grid = [N/2 + 1 z-pass workgroups | HEIGHT | NORMAL | DISP];
+// every dependency is one-way and points to LOWER block indices -- the x-axis workgroups wait for the tile's z-pass workgroups (zdone), the DISP
+// workgroups for the HEIGHT workgroups (hdone) -- and the producers wait for nobody, so nothing can deadlock whatever is resident.  What crosses
+// workgroups inside the launch is stored write-through (`sc1`: the intermediates, the raw heights, the resets of the per-tile words), announced
+// by ONE lane's agent-scope atomic add behind every storing wave's s_waitcnt vmcnt(0) and the workgroup's barrier, and awaited by one lane's
+// `sc1` poll + a barrier (MI355X_MICROARCH.md, inter-workgroup visibility: the measured recipe); the L1 / L2 of the reading side hold none of
+// those lines (invalidated at the launch's start, first touched behind the wait).  The bodies are k_zpass's and k_xpass_b's: the same bits.
+// ============================================================================
+template <int N, int C, int T, class PZ, class PX, bool NTS, bool Z16, bool FAST>
+__global__ void __launch_bounds__(T) k_frame(const FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using HF = Half<N>;
+    constexpr int NZ = N / 2 + 1;
+    constexpr int NB = (HF::NU + C - 1) / C, HB = xpass_height_groups<N, C>();
+    const int bx = (int)blockIdx.x;
+    if (bx < NZ) {
+        zpass_body<N, T, PZ, false, Z16, 1, FAST, true>(a, smem, bx, NZ);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's write-through stores have been taken ...
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.zdone + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... then the workgroup counts itself in
+        return;
+    }
+    xpass_b_body<N, C, T, PX, NTS, Z16, false, true>(a, smem, bx - NZ, (unsigned)(HB + 2 * NB) * gridDim.y, (unsigned)blockIdx.y * (unsigned)(HB + 2 * NB) + (unsigned)(bx - NZ));
 }
 
 template <int N, int C, int T, class P = Plan<N>, bool NTS = false, bool Z16 = false, bool JAC = false>

@@ -150,6 +150,15 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     {   const char* const xm = getenv("OCEAN_XMERGE");            // 0 / 1: force (any size, any batch; still not the Jacobian mode)
         if (xm) merged_x = atoi(xm) != 0 && a.mode != 3 && !split; }
 #endif
+    // ONE launch for the whole frame (k_frame; round 5): pipelined frames of one small tile in the usual form (fp32 spectrum with 16-bit
+    // dispersion, fp32 intermediates, both maps streamed, not the Jacobian mode) -- they are bound by the rate of launches, and the in-launch
+    // hand-offs that cost a SERIAL frame more than its kernel boundaries are hidden behind the other chains' work.
+    constexpr bool HAS_ONE = N <= 512 && G::T_ROWS == G::T_C;
+    [[maybe_unused]] bool one_launch = HAS_ONE && !alone && tiles == 1 && a.mode <= 2 && fast && (stream_maps & 15) == 3 && !split && c->merged_x;
+#ifdef OCEAN_DEVELOPER
+    {   const char* const ol = getenv("OCEAN_ONE_LAUNCH");        // 0 / 1 (the form's own preconditions still hold)
+        if (ol) one_launch = one_launch && atoi(ol) != 0; }
+#endif
     int launches = 0;
     auto next_marks = [&](int kernel) -> hipEvent_t* {      // the event pair of the frame's next launch; remembers which kernel it times
         c->launch_kernel[launches] = kernel;
@@ -270,6 +279,31 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         if (stream_maps & 2) OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, true, da);
         else OCEAN_XPASS(k_xpass_disp, gd, lds_m, md, false, da);
     };
+    if constexpr (HAS_ONE) {
+        if (one_launch) {
+            constexpr size_t lds_one = lds_rows > lds_b ? lds_rows : lds_b;
+            auto kern = k_frame<N, C, G::T_C, typename G::PR, typename G::PC, true, false, true>;
+            if (c->attr_one_n != (uint32_t)N) {
+                if ((e = allow_lds(kern, lds_one)) != hipSuccess) return e;
+                c->attr_one_n = (uint32_t)N;
+            }
+            FrameArgs fa = a;
+            fa.zmask = 15; fa.xb_roles = 7; fa.rec_mode = rec_last; fa.start_ramp = 0;
+            fa.zdone_target = (++c->zgen[c->cur_set]) * (unsigned)(N / 2 + 1);
+            const dim3 grid((N / 2 + 1) + hb_b + 2 * nb, tiles), block(G::T_C);
+            for (int k = 0; k < 3; ++k) {
+                ocean_launch_info& li = c->last_launch[k];
+                li.tile_size = N; li.grid_x = grid.x; li.grid_y = tiles; li.block = G::T_C; li.mode = (uint32_t)a.mode;
+                li.per_workgroup = k == 0 ? 1u : (uint32_t)C;
+                li.lds_bytes = (uint32_t)lds_one;
+                li.flags = OCEAN_LAUNCH_ONE_LAUNCH | (k == 0 ? 0u : (OCEAN_LAUNCH_NT_MAPS | OCEAN_LAUNCH_MERGED_X));
+            }
+            launch(kern, grid, block, lds_one, st, next_marks(0), fa);
+            if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;
+            c->launch_count = launches;
+            return hipGetLastError();
+        }
+    }
     if (!split) {
         if ((e = launch_z(15)) != hipSuccess) return e;
         if (c->after_z && (e = hipEventRecord(c->after_z, st)) != hipSuccess) return e;   // the first frames after a drain: the next chain's z pass starts behind this one (ocean_api.hip)
