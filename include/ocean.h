@@ -437,7 +437,7 @@ enum {
     OCEAN_LAUNCH_WT_INTER        = 2048, /* z pass: fp32 intermediates stored write-through (`sc1`: they leave the XCD's L2 as they are written, no
                                             end-of-kernel write-back burst) -- serial frames at 1024^2 (batches) and 2048^2, single-transform form */
     OCEAN_LAUNCH_ONE_LAUNCH      = 4096, /* the whole frame ran as ONE launch (k_frame: z-pass, height, normal-map and displacement workgroups in one
-                                            grid, one-way hand-offs inside it): pipelined frames of one tile up to 512^2 in the usual form; idx 0..2
+                                            grid, one-way hand-offs inside it): pipelined frames of one tile up to 128^2 in the usual form; idx 0..2
                                             then describe that one launch                                                                    */
     OCEAN_LAUNCH_MERGED_X        = 1024  /* not a kernel variant: k_xpass_b ran the displacement workgroups as well (one launch for the whole x axis,
                                             no k_xpass_disp); set on idx 1 and idx 2, which then describe that one launch                   */

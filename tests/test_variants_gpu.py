@@ -174,9 +174,9 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
             merged = A.OCEAN_LAUNCH_MERGED_X
             assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= (128 if depth == 1 else 512) and tiles == 1 and not jac), what
             # ... and the whole frame as ONE launch (k_frame: the bodies of k_zpass and k_xpass_b in one grid): pipelined frames of one tile up to
-            # 512^2 in the usual form (fp32 spectrum, 16-bit dispersion, fp32 intermediates)
+            # 128^2 in the usual form (fp32 spectrum, 16-bit dispersion, fp32 intermediates)
             one = A.OCEAN_LAUNCH_ONE_LAUNCH
-            want_one = n <= 512 and tiles == 1 and depth > 1 and not (jac or z16 or h16 or w32)
+            want_one = n <= 128 and tiles == 1 and depth > 1 and not (jac or z16 or h16 or w32)
             assert all(bool(li["flags"] & one) == want_one for li in (z, xb, xd)), what
             if want_one:        # (its launch record carries no store-policy flags of the z pass: mapped onto the three-launch variant it replaces)
                 assert z["grid_x"] == xb["grid_x"] == xd["grid_x"] and xb["flags"] & A.OCEAN_LAUNCH_NT_MAPS, what
@@ -273,7 +273,7 @@ def test_jacobian_buffers_are_allocated_by_the_first_frame_of_that_mode():
 
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 512])
+@pytest.mark.parametrize("n", [16, 64, 128, 256, 512])
 def test_merged_x_pass_delivers_the_bits_of_the_three_launch_frame(n, oracles):
     """Round 5: frames of ONE small tile run the whole x axis as one launch -- k_xpass_b with its DISP workgroups, which
     transform pair 0 at once and wait for the tile's HEIGHT workgroups (raw heights handed over write-through inside the launch) only before
@@ -309,7 +309,7 @@ def test_merged_x_pass_delivers_the_bits_of_the_three_launch_frame(n, oracles):
         d2, q2, h2, a2, l2 = frames(True, mode, bits, depth, sync)
         assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l1), what
         # pipelined frames in the usual form go one step further: the whole frame as ONE launch (k_frame)
-        assert all(bool(li["flags"] & A.OCEAN_LAUNCH_ONE_LAUNCH) == (depth > 1 and bits == 32) for li in l2), what
+        assert all(bool(li["flags"] & A.OCEAN_LAUNCH_ONE_LAUNCH) == (n <= 128 and depth > 1 and bits == 32) for li in l2), what
         if n > 128 and depth == 1:          # serial frames from 256^2 up keep three launches (the hand-off costs more than the boundary it replaces)
             assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l2), what
         else:

@@ -1894,8 +1894,8 @@ __global__ void __launch_bounds__(T) k_xpass_b(const FrameArgs a)
 }
 
 // ============================================================================
-// k_frame: a whole frame in ONE launch (round 5) -- for PIPELINED frames of one small tile, which are bound by the rate at which launches get
-// through the process's hardware queues (profiles/r05_small_tile_experiments.txt).  Grid = [N/2 + 1 z-pass workgroups | HEIGHT | NORMAL | DISP];
+// k_frame: a whole frame in ONE launch (round 5) -- for PIPELINED frames of one tile up to 128^2, which are bound by the rate at which launches
+// get through the process's hardware queues (profiles/r05_small_tile_experiments.txt; from 256^2 up the form loses and is not instantiated).  Grid = [N/2 + 1 z-pass workgroups | HEIGHT | NORMAL | DISP];
 // every dependency is one-way and points to LOWER block indices -- the x-axis workgroups wait for the tile's z-pass workgroups (zdone), the DISP
 // workgroups for the HEIGHT workgroups (hdone) -- and the producers wait for nobody, so nothing can deadlock whatever is resident.  What crosses
 // workgroups inside the launch is stored write-through (`sc1`: the intermediates, the raw heights, the resets of the per-tile words), announced

@@ -150,10 +150,12 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     {   const char* const xm = getenv("OCEAN_XMERGE");            // 0 / 1: force (any size, any batch; still not the Jacobian mode)
         if (xm) merged_x = atoi(xm) != 0 && a.mode != 3 && !split; }
 #endif
-    // ONE launch for the whole frame (k_frame; round 5): pipelined frames of one small tile in the usual form (fp32 spectrum with 16-bit
-    // dispersion, fp32 intermediates, both maps streamed, not the Jacobian mode) -- they are bound by the rate of launches, and the in-launch
-    // hand-offs that cost a SERIAL frame more than its kernel boundaries are hidden behind the other chains' work.
-    constexpr bool HAS_ONE = N <= 512 && G::T_ROWS == G::T_C;
+    // ONE launch for the whole frame (k_frame; round 5): pipelined frames of one tile up to 128^2 in the usual form (fp32 spectrum with 16-bit
+    // dispersion, fp32 intermediates, both maps streamed, not the Jacobian mode) -- they are bound by the rate of launches.  Measured at depth 4,
+    // us per frame, three launches / merged x pass / one launch: 64^2 11.5 / 7.6 / 3.9, 128^2 15.0 / 10.3 / 5.2 -- and 256^2 8.2-15.4 / 5.8 / 8.3,
+    // 512^2 11.6-12.3 / 7.7 / 18.6: from 256^2 up the z pass's 8-byte write-through stores and the x-axis workgroups' reads past the L2 cost more
+    // than the launch they save (profiles/r05_small_tile_experiments.txt), so those sizes keep the merged x pass.
+    constexpr bool HAS_ONE = N <= 128 && G::T_ROWS == G::T_C;
     [[maybe_unused]] bool one_launch = HAS_ONE && !alone && tiles == 1 && a.mode <= 2 && fast && (stream_maps & 15) == 3 && !split && c->merged_x;
 #ifdef OCEAN_DEVELOPER
     {   const char* const ol = getenv("OCEAN_ONE_LAUNCH");        // 0 / 1 (the form's own preconditions still hold)
