@@ -388,7 +388,8 @@ int ocean_set_start_ramp(ocean_t* ctx, int on);
  * per frame at depth 4; serial frames up to 128^2 only -- from 256^2 up the in-launch hand-off costs more than the kernel boundary it replaces)
  * and only where every workgroup of that grid is resident at once, one per compute unit; never in OCEAN_MODE_JACOBIAN.  on != 0 (default)
  * allows it, 0 keeps the three-launch frame.  Bit-identical either way; ocean_last_launch marks such a frame with OCEAN_LAUNCH_MERGED_X on
- * idx 1 and 2 (the same launch).                                                                                                          */
+ * idx 1 and 2 (the same launch).  The same switch governs the step beyond it: pipelined frames of one tile up to 128^2 in the usual form run
+ * as ONE launch (OCEAN_LAUNCH_ONE_LAUNCH; 64^2: 11.5 -> 3.9 us per frame at depth 4).                                                                                                          */
 int ocean_set_merged_xpass(ocean_t* ctx, int on);
 
 /* ---- introspection for tests and the bench -------------------------------- */
