@@ -487,7 +487,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set]; a.hdone = c->hdone[set];
-    a.zdone = c->zdone[set]; a.zdone_target = 0; c->cur_set = set;
+    a.zdone = c->zdone[set]; a.zdone_target = 0; a.poll_sleep = 0; c->cur_set = set;
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
     a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
     // the chain's sequence number, tracking and burst state are committed only once the launches have succeeded; a failed enqueue

@@ -155,7 +155,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // us per frame, three launches / merged x pass / one launch: 64^2 11.5 / 7.6 / 3.9, 128^2 15.0 / 10.3 / 5.2 -- and 256^2 8.2-15.4 / 5.8 / 8.3,
     // 512^2 11.6-12.3 / 7.7 / 18.6: from 256^2 up the z pass's 8-byte write-through stores and the x-axis workgroups' reads past the L2 cost more
     // than the launch they save (profiles/r05_small_tile_experiments.txt), so those sizes keep the merged x pass.
-    constexpr bool HAS_ONE = N <= 128 && G::T_ROWS == G::T_C;
+    constexpr bool HAS_ONE = (N <= 128 || (DEV && N <= 512)) && G::T_ROWS == G::T_C;      // (developer builds: up to 512^2, for the A/B of that log)
     [[maybe_unused]] bool one_launch = HAS_ONE && !alone && tiles == 1 && a.mode <= 2 && fast && (stream_maps & 15) == 3 && !split && c->merged_x;
 #ifdef OCEAN_DEVELOPER
     {   const char* const ol = getenv("OCEAN_ONE_LAUNCH");        // 0 / 1 (the form's own preconditions still hold)
@@ -257,6 +257,13 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #endif
         FrameArgs ba = a;
         ba.xb_roles = roles; ba.rec_mode = rec_mode;
+        // the DISP workgroups of a merged launch poll the HEIGHT count; beside other chains' launches a poll every ~3 us instead of back to back
+        // takes the pollers off the memory system (512^2 depth 4: 7.66-7.97 -> 7.35-7.55 us per frame, 256^2 7.8-9.7 -> 7.2-7.3); a serial frame
+        // (<= 128^2) keeps the tight poll -- there the wait IS the frame's latency
+        ba.poll_sleep = ((roles & 4) && !alone) ? 1 : 0;
+#ifdef OCEAN_DEVELOPER
+        if (const char* ps = getenv("OCEAN_POLL_SLEEP")) ba.poll_sleep = atoi(ps);
+#endif
         ba.start_ramp = ramp_b;             // over its normal-map workgroups (the height workgroups start at once)
         if (stream_maps & 1) OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, true, ba);
         else OCEAN_XPASS(k_xpass_b, gb, lds_b, mb, false, ba);
@@ -292,6 +299,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             FrameArgs fa = a;
             fa.zmask = 15; fa.xb_roles = 7; fa.rec_mode = rec_last; fa.start_ramp = 0;
             fa.zdone_target = (++c->zgen[c->cur_set]) * (unsigned)(N / 2 + 1);
+            fa.poll_sleep = 0;
+#ifdef OCEAN_DEVELOPER
+            if (const char* ps = getenv("OCEAN_POLL_SLEEP")) fa.poll_sleep = atoi(ps);
+#endif
             const dim3 grid((N / 2 + 1) + hb_b + 2 * nb, tiles), block(G::T_C);
             for (int k = 0; k < 3; ++k) {
                 ocean_launch_info& li = c->last_launch[k];
