@@ -155,12 +155,20 @@ static int alloc_device(ocean_ctx* c)
     return OCEAN_OK;
 }
 
+// An in-launch wait of a merged / one-launch frame that gave up (ocean_kernels.h: wait_counter) has produced a wrong frame: never silently.
+static int check_fault(ocean_ctx* c)
+{
+    if (c->fault && __atomic_load_n(c->fault, __ATOMIC_ACQUIRE) != 0u) { g_last_hip = (int)hipErrorLaunchTimeOut; return OCEAN_E_HIP; }
+    return OCEAN_OK;
+}
+
 static int sync_all(ocean_ctx* c)
 {
     for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) HIP_TRY(hipStreamSynchronize(c->own[i]));
     if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
     if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    { int rc_ = check_fault(c); if (rc_) return rc_; }
     for (bool& p : c->gather_pending) p = false;
     c->consumer_pending = false;
     c->burst_pos = 0; c->z_last_set = -1;          // the pipeline is empty: the next pipelined frames start staggered (enqueue_frame)
@@ -234,6 +242,8 @@ int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
             if (hipStreamCreateWithFlags(&c->own[i], hipStreamNonBlocking) != hipSuccess) rc = OCEAN_E_HIP;
         if (rc) break;
         if (hipHostMalloc((void**)&c->h_minmax, tiles * 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = OCEAN_E_HIP; break; }
+        if (hipHostMalloc((void**)&c->fault, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { rc = OCEAN_E_HIP; break; }
+        *c->fault = 0u;
         if (hipEventCreate(&c->start_ev) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& e : c->end_ev) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
         for (auto& row : c->mark_ev) for (auto& e : row) if (hipEventCreate(&e) != hipSuccess) { rc = OCEAN_E_HIP; break; }
@@ -254,6 +264,7 @@ void ocean_destroy(ocean_t* c)
     release_import(c);
     free_device(c);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
+    if (c->fault) (void)hipHostFree(c->fault);
     if (c->grid_pos) (void)hipFree(c->grid_pos);
     if (c->mips_disp) (void)hipFree(c->mips_disp);
     if (c->mips_nrm) (void)hipFree(c->mips_nrm);
@@ -438,6 +449,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     c->seed = seed;
     c->prepared = true;
     c->have_frame = false;
+    if (c->fault) *c->fault = 0u;
     return OCEAN_OK;
 }
 
@@ -487,7 +499,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set]; a.hdone = c->hdone[set];
-    a.zdone = c->zdone[set]; a.zdone_target = 0; a.poll_sleep = 0; c->cur_set = set;
+    a.zdone = c->zdone[set]; a.zdone_target = 0; a.poll_sleep = 0; a.fault = c->fault; c->cur_set = set;
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
     a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
     // the chain's sequence number, tracking and burst state are committed only once the launches have succeeded; a failed enqueue
@@ -653,7 +665,7 @@ static int wait_frame(ocean_ctx* c, int set)
         c->h_minmax[2 * i + 0] = rec[i].x;
         c->h_minmax[2 * i + 1] = rec[i].y;
     }
-    return OCEAN_OK;
+    return check_fault(c);
 }
 
 static float amp_of(const ocean_ctx* c, uint32_t tile, float* mn_out, float* mx_out)

@@ -93,6 +93,7 @@ struct ocean_ctx {
     float* h0_inv_scale = nullptr;
     unsigned* h0_maxbits = nullptr;
     unsigned* h_minmax = nullptr;  // pinned
+    unsigned* fault = nullptr;     // host-coherent word the kernels' in-launch waits set when they give up (FrameArgs::fault); sticky until ocean_prepare
     float4* grid_pos = nullptr;     // vertex-stage consumer output (ocean_displace_grid)
     float4* grid_nrm = nullptr;
     uint32_t grid_vertices = 0, grid_capacity = 0;

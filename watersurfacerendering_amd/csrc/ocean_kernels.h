@@ -195,6 +195,7 @@ struct FrameArgs {
     unsigned* zdone;         // [tiles]          z-pass workgroups that have finished, counted up frame after frame (never reset): what the x-axis
                              //                  workgroups of a ONE-LAUNCH frame (k_frame) wait for -- until it has reached zdone_target
     unsigned zdone_target;   //                  (N/2 + 1) x the number of one-launch frames this chain has run, this one included (mod 2^32)
+    unsigned* fault;         // [1] host-coherent: set to 1 by an in-launch wait that gave up after 20 ms (the frame is then wrong: the host reports it)
     int poll_sleep;          //                  in-launch waits: s_sleep 127 (about 3.4 us of a 2.4 GHz clock / 64) repeated this many times between two polls of a counter (0: s_sleep 2)
     unsigned* hdone;         // [tiles]          HEIGHT workgroups of the frame that have finished (reset by the z pass): what the DISP workgroups
                              //                  of a merged x pass wait for (k_xpass_b, xb_roles bit 2)
@@ -1431,28 +1432,35 @@ __device__ __forceinline__ void store_wt(float* p, float v) { __hip_atomic_store
 __device__ __forceinline__ float load_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned load_wt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one lane waits until *ctr has reached `target` (bounded: 20 ms -- a producer that never arrives must not hang the device; the frame is
-// then wrong and the next stream operation still completes), then the workgroup's barrier
-__device__ __forceinline__ void wait_counter(const unsigned* ctr, unsigned target, int tid, int poll_sleep = 0)
+// then wrong, the lane says so in FrameArgs::fault and the host reports an error), then the workgroup's barrier
+__device__ __forceinline__ void wait_counter(const unsigned* ctr, unsigned target, int tid, int poll_sleep = 0, unsigned* fault = nullptr)
 {
     if (tid == 0) {
+#ifdef OCEAN_FAULT_INJECT      // (tools/fault_probe.py: a variant build whose DISP workgroups wait for one arrival too many -- the wait must give up and the host must say so)
+        target += 1u;
+#endif
         const unsigned long long t0 = wall_clock64();
-        while (load_wt(ctr) < target && (wall_clock64() - t0) < 2000000ull) {
+        bool ok;
+        while (!(ok = load_wt(ctr) >= target) && (wall_clock64() - t0) < 2000000ull) {
             if (poll_sleep <= 0) __builtin_amdgcn_s_sleep(2);
             else for (int k = 0; k < poll_sleep; ++k) __builtin_amdgcn_s_sleep(127);
         }
+        if (!ok && fault) *fault = 1u;              // gave up: the host turns this into an error (ocean_api.hip: check_fault)
     }
     __syncthreads();
 }
 
 // the same for a counter that is never reset: until it has REACHED target (mod 2^32: the frames of a chain count it up for ever)
-__device__ __forceinline__ void wait_counter_reached(const unsigned* ctr, unsigned target, int tid, int poll_sleep = 0)
+__device__ __forceinline__ void wait_counter_reached(const unsigned* ctr, unsigned target, int tid, int poll_sleep = 0, unsigned* fault = nullptr)
 {
     if (tid == 0) {
         const unsigned long long t0 = wall_clock64();
-        while ((int)(load_wt(ctr) - target) < 0 && (wall_clock64() - t0) < 2000000ull) {
+        bool ok;
+        while (!(ok = (int)(load_wt(ctr) - target) >= 0) && (wall_clock64() - t0) < 2000000ull) {
             if (poll_sleep <= 0) __builtin_amdgcn_s_sleep(2);
             else for (int k = 0; k < poll_sleep; ++k) __builtin_amdgcn_s_sleep(127);
         }
+        if (!ok && fault) *fault = 1u;
     }
     __syncthreads();
 }
@@ -1604,7 +1612,7 @@ __device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* 
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     // a launch holds the HEIGHT workgroups, the NORMAL workgroups or (usually) both: a.xb_roles; bx = the index in the full grid
     const int bx = bx_in + (a.xb_roles == 2 ? HB : 0);
-    if constexpr (ONE) wait_counter_reached(a.zdone + tile, a.zdone_target, tid, a.poll_sleep);      // the intermediates of THIS frame are all written (write-through)
+    if constexpr (ONE) wait_counter_reached(a.zdone + tile, a.zdone_target, tid, a.poll_sleep, a.fault);      // the intermediates of THIS frame are all written (write-through)
 
     // (the roles are lambdas: every workgroup of a launch, whatever its role, ends in frame_records)
     auto pair3_role = [&]() {
@@ -1865,7 +1873,7 @@ __device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* 
 #pragma unroll
                     for (int i = 0; i < LSD::RL; ++i) dheld[u][i] = make_float2(0.0f, 0.0f);
             }
-            wait_counter(a.hdone + tile, (unsigned)HB, tid, a.poll_sleep);
+            wait_counter(a.hdone + tile, (unsigned)HB, tid, a.poll_sleep, a.fault);
             const unsigned kmn = load_wt(a.minmax + 2 * tile + 0), kmx = load_wt(a.minmax + 2 * tile + 1);      // final: every HEIGHT workgroup has counted itself in
             const float mn = key_float(kmn), mx = key_float(kmx);
             const float inv_a = 1.0f / fmaxf(fabsf(mn), fabsf(mx));
