@@ -391,6 +391,9 @@ int ocean_set_start_ramp(ocean_t* ctx, int on);
  * idx 1 and 2 (the same launch).  The same switch governs the step beyond it: pipelined frames of one tile up to 128^2 in the usual form run
  * as ONE launch (OCEAN_LAUNCH_ONE_LAUNCH; 64^2: 11.5 -> 3.9 us per frame at depth 4).                                                                                                          */
 int ocean_set_merged_xpass(ocean_t* ctx, int on);
+/* (Failure mode of those in-launch waits: a workgroup that has waited 20 ms for its producers gives up -- the device never hangs -- and sets a
+ * host-coherent word; ocean_wait_frame, ocean_synchronize and every read-out then return OCEAN_E_HIP (ocean_last_hip_error:
+ * hipErrorLaunchTimeOut) instead of handing out the frame, until the next ocean_prepare.  Never observed outside the fault-injection build.) */
 
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */

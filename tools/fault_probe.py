@@ -28,8 +28,8 @@ try:
     sys.exit(1)
 except W.OceanError as e:
     print("read-out refused:", e.code)
+b.prepare(3)                                    # the fault is sticky until the next Prepare, which drains the context and clears it
 b.set_pipeline_depth(1)                         # a serial 512^2 frame keeps three launches: no in-launch wait
-b.prepare(3)                                    # (clears the flag)
 amp = b.compute_waves(0.5)
 print("serial frame after re-Prepare fine: A =", float(amp[0]))
 b.close()

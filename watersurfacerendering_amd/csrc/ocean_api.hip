@@ -342,6 +342,10 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
+    // a fault an in-launch wait reported (check_fault) is sticky until the next Prepare: drain what is in flight, then start clean
+    for (int i = 0; i < MAXD; ++i) if (c->own[i]) (void)hipStreamSynchronize(c->own[i]);
+    if (c->user) (void)hipStreamSynchronize(c->user);
+    if (c->fault) *c->fault = 0u;
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     std::vector<TileParams> tp(t);
     for (size_t i = 0; i < t; ++i) {
