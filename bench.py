@@ -19,12 +19,15 @@ With --depth 3 (default) consecutive frames rotate over three independent chains
 intermediates, own map set); every frame is still computed in full.  --depth 1 = strictly serial
 frames (also reported under extra).
 
-roofline: per-launch durations are the kernels' own execution times (events attached to the
-dispatches with hipExtLaunchKernelGGL on the launch stream, serial frames so that every kernel has
-the GPU to itself); bytes are what THIS pipeline has to move (73 B/texel: 23 / 28 / 22 per launch),
-with the PMC-measured traffic (profiles/traffic.json) and the rocprofv3 duration of the same
-kernel (profiles/kernel_stats.json) beside them.  SURVEY.md 8d's 108 B/texel figure is reported
-separately and labelled as a model, not traffic.
+roofline: per-launch durations are the kernels' own execution times (events attached to the dispatches with hipExtLaunchKernelGGL on the
+launch stream, serial frames in a context of their own so that every kernel has the GPU to itself; three such passes spread over the run --
+before the timed regions, right behind them, at the end -- and the one with the median frame time is reported, all three in the sidecar);
+bytes are what THIS pipeline has to move (73 B/texel: 23 / 28 / 22 per launch), with the PMC-measured traffic (profiles/traffic.json) and the
+rocprofv3 duration of the same kernel (profiles/kernel_stats.json) beside them while the kernel sources hash to what those were measured with.
+
+Output: rank 0 prints ONE compact JSON line on stdout (the contract's keys + roofline / cpu_baseline / gather / timing objects, numbers and
+short labels only, < 8 KB: tests/test_bench_contract.py asserts it) and writes everything else it measured -- the secondary configurations,
+per-kernel tables, the CPU baseline's stage split, every explanatory note -- to bench_extra.json beside this script and to stderr.
 
 Multi-GPU: tiles are independent, so every rank synthesises its own tile(s) with no data-path
 collective ("weak" scaling, value = frames of all ranks per second).  The north-star's single RCCL
@@ -39,7 +42,7 @@ BASELINE config 5 (64 independent 1024 x 1024 tiles, 8 per GPU on 8 GPUs) as the
 (`config.workload` then reads "64 x 1024x1024 tiles, 8 per GPU"); the default invocation keeps BASELINE's single-GPU
 headline tile (2048 x 2048) per rank and measures config 5's share in the `gather` object.
 
-Rank 0 prints ONE JSON line.  Exit status: 0 only when the line carries every measurement that was asked for; a gather
+Exit status: 0 only when the line carries every measurement that was asked for; a gather
 that hangs or fails at N > 1 still gets its line out (the timed region is complete by then) but the process exits 3.
 """
 from __future__ import annotations
