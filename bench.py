@@ -270,6 +270,19 @@ def cpu_baseline(n: int, budget_s: float):
     return ref_shape, strong
 
 
+def cpu_child_env(environ):
+    """Environment of the CPU-baseline child.  torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks whenever it starts more than
+    one of them (and the driver starts bench.py that way at N > 1): inherited, it would time the reference's OpenMP path on ONE thread
+    and the N > 1 lines would carry a CPU figure 7-16x below the N = 1 line's.  Under the launcher the variable is dropped, so the child
+    sizes its team from the usable CPUs as it does at N = 1 (`cores` in the line is what it really used)."""
+    env = dict(environ, OMP_WAIT_POLICY="PASSIVE")
+    if "TORCHELASTIC_RUN_ID" in env or "LOCAL_WORLD_SIZE" in env:
+        env.pop("OMP_NUM_THREADS", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)                        # the child is no rank of anything
+    return env
+
+
 def cpu_baseline_isolated(n: int, budget_s: float, check_file=None):
     """The CPU baseline leg in a child process with a hard time limit: the oracle is test infrastructure running on a
     host this script knows nothing about, and nothing it does may hang or take down the GPU measurement.  With check_file the
@@ -279,9 +292,9 @@ def cpu_baseline_isolated(n: int, budget_s: float, check_file=None):
     if check_file:
         cmd += ["--check-file", check_file]
         limit += 240
+    env = cpu_child_env(os.environ)
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit,
-                           env=dict(os.environ, OMP_WAIT_POLICY="PASSIVE"))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, env=env)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and lines:
             d = json.loads(lines[-1])
@@ -695,6 +708,13 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
         ok = ok and all(abs(g - w) <= 1e-6 * max(1.0, abs(w)) for g, w in zip(got, want))
     b.comm_destroy()
     b.close()
+    return gather_report(n, tiles, world, rccl_ranks, rccl_rank, compute, serial, overlapped, overlapped16, ok)
+
+
+def gather_report(n, tiles, world, rccl_ranks, rccl_rank, compute_s, serial_s, overlapped_s, overlapped16_s, ok):
+    """measure_gather's result as a dictionary (pure: the seconds per step of the four regimes in, SURVEY.md 8e's figures out).  Kept apart
+    from the measurement so that the CPU contract test builds the N > 1 line from exactly what a real run would hand to build_line
+    (tests/line_schema.py checks both)."""
     per_rank = tiles * n * n * 4 * 4 * 2
     total = world * tiles
     return {"what": "BASELINE config 5 share: 8 tiles of 1024x1024 per rank per step; ocean_gather_maps = ncclGather x 2 "
@@ -704,12 +724,12 @@ def measure_gather(W, torch, dist, wdist, dev, local_rank, world, rank, backend,
             "tile_size": n, "tiles_per_rank": tiles, "ranks": world, "rccl_ranks_seen": rccl_ranks, "rccl_rank_of_root": rccl_rank,
             "bytes_per_rank_per_step": per_rank,
             "bytes_into_root_per_step": per_rank * (world - 1),
-            "compute_only": {"ms_per_step": compute * 1e3, "tiles_per_s": total / compute},
-            "compute_plus_gather_serial": {"ms_per_step": serial * 1e3, "tiles_per_s": total / serial},
-            "compute_gather_overlapped": {"ms_per_step": overlapped * 1e3, "tiles_per_s": total / overlapped},
-            "compute_gather_overlapped_half_maps": {"ms_per_step": overlapped16 * 1e3, "tiles_per_s": total / overlapped16,
+            "compute_only": {"ms_per_step": compute_s * 1e3, "tiles_per_s": total / compute_s},
+            "compute_plus_gather_serial": {"ms_per_step": serial_s * 1e3, "tiles_per_s": total / serial_s},
+            "compute_gather_overlapped": {"ms_per_step": overlapped_s * 1e3, "tiles_per_s": total / overlapped_s},
+            "compute_gather_overlapped_half_maps": {"ms_per_step": overlapped16_s * 1e3, "tiles_per_s": total / overlapped16_s,
                                                     "what": "ocean_gather_maps_f16: maps converted to IEEE half on the sender, 16 B/texel on the wire"},
-            "root_ingest_GBps_overlapped": per_rank * (world - 1) / overlapped * 1e-9,
+            "root_ingest_GBps_overlapped": per_rank * (world - 1) / overlapped_s * 1e-9,
             "root_copy_matches_local_maps": ok}
 
 
@@ -855,10 +875,13 @@ def main():
     serial_pass("right behind the timed regions")
 
     def make_roofline():
-        frame_us, kern = sorted(serial_passes, key=lambda p: p[0])[(len(serial_passes) - 1) // 2][:2]
+        # (the median of an odd number of passes; of an even number -- the line the gather watchdog emits before the last pass -- the SLOWER
+        #  middle one: never the optimistic pass under a 'median' label)
+        frame_us, kern = sorted(serial_passes, key=lambda p: p[0])[len(serial_passes) // 2][:2]
         r = roofline_object(n, tiles, names, kern, kern_ms_pipe, args.depth, ms_per_step, frame_us, own_bpt, kernel_bytes)
         r["serial_pass"] = ("contexts of their own at pipeline depth 1 (the synchronous-call configuration), 300 warm-up + 200 timed frames each; one before "
                             "the timed regions, one right behind them, one at the end of the run (rank 0): the one with the median frame time is reported")
+        r["serial_passes_used"] = len(serial_passes)
         r["serial_passes_us"] = [{"when": p[2], "frame": p[0], **{k: v * 1e3 for k, v in zip(names, p[1])}} for p in serial_passes]
         if kern_ms_main is not None:
             r["serial_kernels_in_bench_context_us"] = {k: v * 1e3 for k, v in zip(names, kern_ms_main)}

@@ -7,6 +7,8 @@ import sys
 
 import pytest
 
+import line_schema
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -49,19 +51,15 @@ def _full_run(bench, argv=()):
     a = bench.parse(list(argv))
     names = ["k_zpass", "k_xpass_b", "k_xpass_disp"]
     n, tiles = a.size, a.tiles
-    roof = bench.roofline_object(n, tiles, names, [0.0221234567, 0.0200345678, 0.0166456789], [0.0349, 0.0492, 0.0349], a.depth, 0.0498765432, 58.123456789, 73.0,
-                                 dict(zip(names, (23, 28, 22))))
+    w = tiles * n * n / 2048 ** 2                      # (durations scaled with the work of one launch: 8 x 1024^2 is twice a 2048^2 tile)
+    roof = bench.roofline_object(n, tiles, names, [0.0221234567 * w, 0.0200345678 * w, 0.0166456789 * w], [0.0349 * w, 0.0492 * w, 0.0349 * w], a.depth,
+                                 0.0498765432 * w, 58.123456789 * w, 73.0, dict(zip(names, (23, 28, 22))))
     cpu = {"value": 22.643211234, "unit": "frames/s", "cores": 16, "nproc": 256, "kind": "port", "fft": "own", "cores_note": "x" * 300,
            "sample": "20 frames of the same 2048x2048 7-field workload after 2 warm-up frames, median (44.2 ms/frame); FFTW not available on this host: " + "y" * 400,
            "stage_ms_of_the_median_frame": {"spectra": 1.0, "fft": 40.0, "pack": 2.0, "normalise": 1.2}, "gtexels_per_s": 0.0949, "host": {"cpu_model": "z" * 60, "nproc": 256},
            "config1_256x256_height_only_cpu_ms": 0.9}
     strong = dict(cpu, value=66.6123456789, cores=64, candidates_ms_per_frame={f"candidate {i} " + "c" * 80: 15.0 + i for i in range(10)})
-    gather = {"what": "w" * 400, "transport": "RCCL", "tile_size": 1024, "tiles_per_rank": 8, "ranks": 8, "rccl_ranks_seen": 8, "rccl_rank_of_root": 0,
-              "bytes_per_rank_per_step": 268435456, "bytes_into_root_per_step": 1879048192,
-              "compute_only": {"ms_per_step": 0.118, "tiles_per_s": 5.4e5}, "compute_plus_gather_serial": {"ms_per_step": 3.9, "tiles_per_s": 1.6e4},
-              "compute_gather_overlapped": {"ms_per_step": 3.6, "tiles_per_s": 1.78e4},
-              "compute_gather_overlapped_half_maps": {"ms_per_step": 1.9, "tiles_per_s": 3.4e4, "what": "h" * 100},
-              "root_ingest_GBps_overlapped": 522.123, "root_copy_matches_local_maps": True}
+    gather = bench.gather_report(1024, 8, 8, 8, 0, 0.118e-3, 3.9e-3, 3.6e-3, 1.9e-3, True)      # what measure_gather hands over on 8 ranks
     timing = {"regions": 9, "steps_per_region": a.steps, "statistic": "median over the regions", "ms_per_step_median": 0.0498765432, "ms_per_step_mean": 0.0501,
               "ms_per_step_p10": 0.0484, "ms_per_step_p90": 0.0504, "ms_per_step_min": 0.048, "ms_per_step_max": 0.052,
               "ms_per_step_of_each_region_in_order": [0.05] * 9, "what": "t" * 300}
@@ -90,7 +88,9 @@ def test_stdout_line_is_compact_strict_json_and_the_rest_goes_to_the_sidecar(ben
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-5)
         assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "nproc", "kind", "fft", "sample"} and len(back["cpu_baseline"]["sample"]) <= 160
         assert back["cpu_baseline_strong"]["value"] == pytest.approx(66.6123, rel=1e-4)
-        assert back["gather"]["rccl_ranks_seen"] == 8 and back["gather"]["compute_gather_overlapped_tiles_per_s"] == pytest.approx(1.78e4)
+        assert back["gather"]["rccl_ranks_seen"] == 8 and back["gather"]["compute_gather_overlapped_tiles_per_s"] == pytest.approx(64 / 3.6e-3, rel=1e-5)
+        line_schema.check_contract_line(back, world)
+        line_schema.check_gather(back["gather"], 8)
         assert back["timing"]["ms_per_step_p10"] <= back["ms_per_step"] <= back["timing"]["ms_per_step_p90"] and back["timing"]["regions"] == 9
         assert back["sidecar"] == bench.SIDECAR and back["build_id"] == "a5cbb90d78459412" and len(back["kernel_source_sha16"]) == 16
         side = bench.build_sidecar(line, a, roof, gather, extra, cpu, strong, timing)
@@ -114,8 +114,18 @@ def test_multi_gpu_line_carries_config5_workload_cpu_baseline_and_roofline(bench
     roof = bench.roofline_object(1024, 8, names, [0.045, 0.04, 0.03], [0.06, 0.05, 0.04], 2, 0.11, 120.0, 73.0,
                                  dict(zip(names, (23, 28, 22))))
     cpu = {"value": 20.0, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "synthetic"}
-    gather = {"ranks": 8, "rccl_ranks_seen": 8, "compute_only": {"tiles_per_s": 5e5}}
+    gather = bench.gather_report(1024, 8, 8, 8, 0, 64 / 5e5, 3.9e-3, 3.6e-3, 1.9e-3, True)
     line = bench.build_line(a, 8, 1024, 8, 5.6e5, 0.11, roof, gather, cpu, dict(cpu, value=80.0))
+    # the SAME checks tests/test_zz_multi_gpu.py runs on the line of a real multi-GPU run (tests/line_schema.py): a key renamed in
+    # bench.py fails here, on the CPU box, and not in the harness of the first 8-GPU run
+    line_schema.check_multi_gpu_line(json.loads(bench.encode_line(line)), 8)
+    for world in (2, 4):
+        g = bench.gather_report(1024, 8, world, world, 0, 0.12e-3, 1.0e-3 * world, 0.9e-3 * world, 0.5e-3 * world, True)
+        line_schema.check_multi_gpu_line(json.loads(bench.encode_line(bench.build_line(bench.parse(["--gpus", str(world)]), world, 2048, 1, 4e4, 0.05, roof, g, cpu, None))), world)
+    with pytest.raises(AssertionError):
+        line_schema.check_gather({"error": "the gather measurement did not finish within 240 s"}, 8)
+    with pytest.raises(AssertionError):                 # the round-5 shape of the gather object (nested) is what the GPU test still read: refused now
+        line_schema.check_gather(dict(line["gather"], compute_only={"tiles_per_s": 5e5}, compute_only_tiles_per_s=None), 8)
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32"
     assert line["config"]["workload"].startswith("64 x 1024x1024 tiles, 8 per GPU") and "BASELINE config 5" in line["config"]["workload"]
     assert line["config"]["tiles_per_rank"] == 8 and line["config"]["pipeline_depth"] == 2
@@ -123,7 +133,7 @@ def test_multi_gpu_line_carries_config5_workload_cpu_baseline_and_roofline(bench
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["kernel"] in names
     assert r["algorithmic_bytes_per_launch"] == r["kernels"][r["kernel"]]["bytes_per_texel"] * 1024 * 1024 * 8
-    assert line["gather"]["rccl_ranks_seen"] == 8 and line["gather"]["compute_only_tiles_per_s"] == 5e5
+    assert line["gather"]["rccl_ranks_seen"] == 8 and line["gather"]["compute_only_tiles_per_s"] == pytest.approx(5e5)
     assert line["warmup"] == 20 and line["prewarm_frames"] == a.prewarm
     bench.encode_line(line)
     # a single-GPU single-tile line still names the headline tile
@@ -323,3 +333,11 @@ def test_bench_py_refers_to_no_undefined_global(bench):
             walk(child)
     walk(top)
     assert not missing, missing
+
+
+def test_cpu_baseline_child_does_not_inherit_the_launchers_single_thread(bench):
+    """torch.distributed.run sets OMP_NUM_THREADS=1 for its ranks at nproc > 1: the CPU leg of an N > 1 run must not be timed on one thread."""
+    env = bench.cpu_child_env({"OMP_NUM_THREADS": "1", "TORCHELASTIC_RUN_ID": "x", "RANK": "0", "WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8", "PATH": "/usr/bin"})
+    assert "OMP_NUM_THREADS" not in env and "RANK" not in env and "WORLD_SIZE" not in env and env["OMP_WAIT_POLICY"] == "PASSIVE" and env["PATH"] == "/usr/bin"
+    # a user's own setting outside the launcher stands
+    assert bench.cpu_child_env({"OMP_NUM_THREADS": "4"})["OMP_NUM_THREADS"] == "4"

@@ -2,12 +2,13 @@
 skipped otherwise (a gpurun box has one).  The file sorts last on purpose: on a multi-GPU node these are the first runs of the
 gather over xGMI anywhere, and `pytest -x` must not let a surprise there hide the parity results.  One process per GPU, the library's own RCCL communicator
 (ocean_comm_init / ocean_gather_maps), every rank's tiles compared on the root bit for bit."""
-import json
 import os
 import subprocess
 import sys
 
 import pytest
+
+import line_schema
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,12 +44,9 @@ def test_bench_two_gpus_over_rccl():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "50", "--prewarm", "100",
                         "--no-extra", "--cpu-seconds", "1"], capture_output=True, text=True, env=_env(), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]          # a gather that fails or hangs exits non-zero (bench.py: give_up / failed)
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["cpu_baseline"]["value"] > 0
-    g = out["gather"]
-    assert "error" not in g
-    assert g["ranks"] == 2 and g["rccl_ranks_seen"] == 2 and g["root_copy_matches_local_maps"] is True
-    assert g["compute_only"]["tiles_per_s"] > g["compute_plus_gather_serial"]["tiles_per_s"] > 0
+    out = line_schema.last_json_line(r.stdout)
+    # (the keys checked here are the ones tests/test_bench_contract.py checks on a synthetic world-8 line: one schema, tests/line_schema.py)
+    line_schema.check_multi_gpu_line(out, 2)
 
 
 def _build_gather_demo(tmp_path):
@@ -69,10 +67,9 @@ def test_bench_config5_invocation_on_eight_gpus():
                         "--steps", "200", "--warmup", "50", "--prewarm", "100", "--no-extra", "--cpu-seconds", "1"],
                        capture_output=True, text=True, env=_env(), timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 8 and "BASELINE config 5" in out["config"]["workload"] and out["value"] > 0
-    assert "error" not in out["gather"] and out["gather"]["rccl_ranks_seen"] == 8 and out["gather"]["root_copy_matches_local_maps"] is True
-    assert out["roofline"]["frac"] < 1.0 and out["cpu_baseline"]["value"] > 0
+    out = line_schema.last_json_line(r.stdout)
+    line_schema.check_multi_gpu_line(out, 8)
+    assert "BASELINE config 5" in out["config"]["workload"] and out["config"]["pipeline_depth"] == 2
 
 
 @pytest.mark.parametrize("ranks", [1, 2, 8])
