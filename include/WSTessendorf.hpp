@@ -107,9 +107,10 @@ public:
     {
         if (m_Pending) Wait();
         float amp = 0.f;
-        Check(ocean_compute_waves(m_Ctx, time, &amp), "ocean_compute_waves");
-        Check(ocean_read_maps(m_Ctx, 0, 1, reinterpret_cast<float*>(m_Displacements[m_Front].data()),
-                              reinterpret_cast<float*>(m_Normals[m_Front].data())), "ocean_read_maps");
+        // synthesis + both maps into the host vectors, one blocking call: the normal map's copy runs beside the displacement pass
+        // (ocean_compute_waves_read; the same maps as ocean_compute_waves + ocean_read_maps)
+        Check(ocean_compute_waves_read(m_Ctx, time, &amp, reinterpret_cast<float*>(m_Displacements[m_Front].data()),
+                                       reinterpret_cast<float*>(m_Normals[m_Front].data())), "ocean_compute_waves_read");
         float a;
         Check(ocean_get_heights(m_Ctx, 0, &a, &m_MinHeight, &m_MaxHeight), "ocean_get_heights");
         return amp;
@@ -117,7 +118,7 @@ public:
 
     // Opt-in non-blocking pair, beyond the reference -- whose own note on its DOUBLE_BUFFERED switch says "should be on dedicated
     // thread" (WaterSurfaceMesh.h:26-34): ComputeWaves above is synthesis + a blocking copy of both maps to the host, and the copy
-    // is 10-40 x the synthesis (213 us at 512^2, 2.5 ms at 2048^2).  ComputeWavesAsync enqueues the frame and the DMA of both maps
+    // is 10-40 x the synthesis (INTEGRATION.md section A has the measured call).  ComputeWavesAsync enqueues the frame and the DMA of both maps
     // into a BACK pair of host vectors and returns A as soon as the frame's kernels have finished (ocean_wait_frame: a poll of
     // the frame's completion records) -- the copy is still in flight.  Wait() blocks until it has landed and makes that pair the
     // front one.  In between, GetDisplacements() / GetNormals() / GetMinHeight() / GetMaxHeight() keep returning the previous
@@ -152,6 +153,7 @@ public:
     }
     bool Pending() const { return m_Pending; }
 
+#ifdef OCEAN_DEV_H_      // (only for a host that included the developer header first: ocean_select_streams is bench plumbing, not part of the boundary)
     // Opt-in, once after Prepare(): put the model's work on the fastest of the process's hardware queues (ocean_select_streams: the queues
     // of an MI355X process differ by up to 1 us per kernel).  Costs 4 x 55 frames; the next ComputeWaves delivers as ever.
     void SelectFastestQueue(uint32_t framesPerQueue = 50)
@@ -159,6 +161,7 @@ public:
         Wait();
         Check(ocean_select_streams(m_Ctx, framesPerQueue, nullptr), "ocean_select_streams");
     }
+#endif
 
     // Getters: WSTessendorf.h:82-107
     auto GetTileSize() const { return ocean_tile_size(m_Ctx); }

@@ -22,6 +22,12 @@
  *       normal       = (dh/dx, dh/dz, dDx/dx, dDz/dz)        WSTessendorf.cpp:414-437
  *   - there is NO CPU fallback: every call fails with OCEAN_E_NO_DEVICE /
  *     OCEAN_E_HIP when no gfx950 device is usable.
+ *
+ * This header is the drop-in boundary (lifetime, properties, Prepare, ComputeWaves, read-out, the upload path of 8f rank 1,
+ * the output modes, the RCCL gather of 8e).  Two more headers declare the rest of what libocean_hip.so exports:
+ *   include/ocean_consumers.h   SURVEY.md 8f ranks 3-4: the vertex-stage consumer, cascades, the mip chain
+ *   include/ocean_dev.h         what tests, bench.py and the A/B tools under tools/ use and a renderer never needs: Prepare() read-backs,
+ *                               per-kernel timing, what the last frame launched, the switches of the launch heuristics
  */
 #ifndef OCEAN_H_
 #define OCEAN_H_
@@ -33,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 4   /* 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp, ocean_set_merged_xpass (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
+#define OCEAN_ABI_VERSION 5   /* 5: round 6 -- ocean_compute_waves_read, ocean_fault_recoveries added; the vertex-stage / mip consumers moved to ocean_consumers.h and the bench / A-B plumbing to ocean_dev.h (same symbols, same library); 4: round 5 -- ocean_build_id, ocean_set_external_readers, ocean_set_start_ramp, ocean_set_merged_xpass (additions only); 2: round 2 -- gather, Jacobian mode, half2 intermediates, staging read-out, cascades, mips; 3: round 3 -- ocean_wait_frame,
                                  ocean_set_frame_tracking, ocean_last_launch, ocean_export_maps, ocean_bind_output_dmabuf, ocean_select_streams,
                                  ocean_comm_count, ocean_algorithmic_bytes_per_launch (additions only) */
 
@@ -74,6 +80,16 @@ int         ocean_abi_version(void);
 const char* ocean_build_id(void);
 /* hipError_t value of the most recent failing HIP call on this thread (0 if none). */
 int         ocean_last_hip_error(void);
+/* Frames of single small tiles may run several dependent stages in ONE launch, later workgroups waiting for earlier ones inside it (pipelined
+ * frames up to 512^2, serial ones up to 128^2; only where the whole grid is resident at once, one workgroup per compute unit).  Such a wait
+ * is bounded: a workgroup that has waited 20 ms for its producers -- a device shared or time-sliced with other work can switch them out --
+ * gives up, the device never hangs.  The host then RECOVERS: the next ocean_wait_frame / ocean_compute_waves / ocean_synchronize / read-out
+ * drains the context, keeps the three-launch frame for this context from then on and runs the affected frames again (same time, same chain),
+ * so the call returns the frame it was asked for; this counter says how often that happened (0 on a dedicated device: never observed outside
+ * the fault-injection build).  Only a stream-ordered consumer enqueued behind such a frame (ocean_gather_maps, ocean_displace_grid,
+ * ocean_build_mips) cannot be redone: the recovering call returns OCEAN_E_HIP (ocean_last_hip_error: hipErrorLaunchTimeOut) ONCE, the context
+ * stays usable and the consumer call is the caller's to repeat.                                                                           */
+unsigned    ocean_fault_recoveries(const ocean_t* ctx);
 
 /* ---- lifetime: replaces WSTessendorf::WSTessendorf / ~WSTessendorf
  *      (WSTessendorf.cpp:13-34).  tile_size must be a power of two in
@@ -152,6 +168,14 @@ int ocean_get_heights(ocean_t* ctx, uint32_t tile, float* amp, float* min_h, flo
  *      Vulkan staging pointer); N*N*4 floats per tile, tile-major.  Either may
  *      be NULL.  Synchronous.                                                    */
 int ocean_read_maps(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);
+/* ComputeWaves(t) AND the read-out of every tile's maps in one blocking call -- the reference's call shape, one ComputeWaves followed by two
+ * memcpy's of the finished maps (WaterSurfaceMesh.cpp:145-154, 701-755): out_amp[tiles] (may be NULL), disp / nrm = tiles*N*N*4 floats each
+ * (neither NULL).  Same results as ocean_compute_waves + ocean_read_maps(0, tiles), sooner: the normal map is final when the frame's second
+ * launch ends, so its device-to-host copy runs on a copy stream beside the displacement pass, and the displacement map's copy follows behind
+ * its kernel on the frame's stream -- two DMA engines, one PCIe link kept busy from the second launch on; the call returns from a poll of
+ * the two copies' events, not from a stream synchronisation.  Register the destinations with ocean_host_register for true DMAs (pageable
+ * memory still works: staged, blocking copies).                                                                                            */
+int ocean_compute_waves_read(ocean_t* ctx, float t, float* out_amp, float* disp, float* nrm);
 
 /* Asynchronous read-out (the upload path after ComputeWaves,
  * WaterSurfaceMesh.cpp:701-755 + vulkan/Buffer.cpp:133-155).  ocean_host_register pins a
@@ -283,47 +307,6 @@ int ocean_set_intermediate_precision(ocean_t* ctx, int bits);
  * DOUBLE_BUFFERED switch, WaterSurfaceMesh.h:34, is the same idea on the upload side.)  */
 int ocean_set_pipeline_depth(ocean_t* ctx, int depth /* 1 .. 8 */);
 
-/* ---- vertex-stage consumer ----------------------------------
- * What the reference's vertex shader does with the two maps
- * (src/shaders/WaterSurfaceMesh.vert:24-41) for the grid its mesh generator builds
- * (WaterSurfaceMesh::CreateGridVertices, WaterSurfaceMesh.cpp:500-533), on the device:
- * vertex (x, y), x, y = -grid_size/2 .. grid_size/2, sits at (x, 0, y) * vertex_distance with
- * uv = (x + half, y + half) / grid_size; both maps are sampled at uv * uv_scale with the
- * reference's sampler (LINEAR, REPEAT: vulkan/Sampler.cpp:60-66);
- *   position = inPos + (D.x, D.y * A, D.z), w = D.w          (A = amplitude of the frame)
- *   normal   = normalize(-s.x / (1 + choppy*s.z), 1, -s.y / (1 + choppy*s.w)), w = 0
- * for the most recent frame of `tile`, ordered on its stream.  choppy is the value the
- * reference feeds (GetDisplacementLambda(), WaterSurfaceMesh.cpp:172).  Results stay in
- * device buffers owned by the context ((grid_size+1)^2 float4 each): ocean_read_grid copies
- * them out (synchronises), ocean_device_grid hands out the pointers.                  */
-int ocean_displace_grid(ocean_t* ctx, uint32_t tile, uint32_t grid_size, float vertex_distance,
-                        float uv_scale, float choppy);
-/* Cascades (the reference's to-do "Endless - solving the tiling artifacts", README.md:37-44): the
- * tiles first_tile .. first_tile+count-1 of the batch (count <= 8) -- independent oceans with their own tile length,
- * wind, seed -- are summed by the consumer, tile c sampled at uv * uv_scales[c]:
- *   position = inPos + sum_c (D_c.x, D_c.y * A_c, D_c.z),  w = min_c D_c.w
- *   normal   = normalize(-S.x / (1 + choppy*S.z), 1, -S.y / (1 + choppy*S.w)),  S = sum_c normal-map sample of tile c
- * With incommensurate scales the surface no longer repeats with the period of one tile.  Same output buffers
- * and read-out as ocean_displace_grid.                                                                          */
-int ocean_displace_grid_cascades(ocean_t* ctx, uint32_t first_tile, uint32_t count, uint32_t grid_size,
-                                 float vertex_distance, const float* uv_scales /* count */, float choppy);
-int ocean_read_grid(ocean_t* ctx, float* positions, float* normals);
-int ocean_device_grid(ocean_t* ctx, void** d_positions, void** d_normals, uint32_t* vertices);
-
-/* Mip chain of one tile's maps: the reference's LOD hook.  Its map textures are created and filled with a
- * `mipmapping` flag (s_kUseMipMapping, WaterSurfaceMesh.h:216, passed at WaterSurfaceMesh.cpp:611-618,652-690; off in the
- * shipped build, "LOD. anti-aliasing" on its to-do list, README.md:37-44); when set, Texture2D::GenerateMipmaps
- * (vulkan/Texture2D.cpp:228-330) blits level i-1 into level i at half the extent with VK_FILTER_LINEAR,
- * floor(log2(N)) + 1 levels in all.  ocean_build_mips does the same for both maps of `tile` behind the frame that wrote
- * them: levels 1 .. log2(N) (level 0 is the map itself), each texel the 2 x 2 mean of the level above, tightly packed
- * one after another -- level l starts at texel sum_{k=1}^{l-1} (N >> k)^2, ocean_mip_texels(N) = (N^2 - 1) / 3 texels
- * of RGBA32F per map.  Results stay in device buffers owned by the context: ocean_read_mips copies them out
- * (synchronises), ocean_device_mips hands out the pointers and the number of levels.                                  */
-size_t ocean_mip_texels(uint32_t tile_size);
-int ocean_build_mips(ocean_t* ctx, uint32_t tile);
-int ocean_read_mips(ocean_t* ctx, float* disp_mips, float* nrm_mips);
-int ocean_device_mips(ocean_t* ctx, void** d_disp_mips, void** d_nrm_mips, uint32_t* levels);
-
 /* The hipStream_t the most recent frame was enqueued on (as void*), and a way
  * to make the context use ONE caller-owned stream instead (this also disables
  * pipelining; NULL = back to the context's own streams).                         */
@@ -364,106 +347,6 @@ int ocean_gather_maps(ocean_t* ctx, int root, void* d_recv_disp, void* d_recv_nr
 int ocean_gather_maps_f16(ocean_t* ctx, int root, void* d_recv_disp, void* d_recv_nrm);
 /* ncclResult_t of the most recent failing RCCL call on this thread (0 if none).                 */
 int ocean_last_rccl_error(void);
-
-/* Optional, once after ocean_prepare: put the context's work on the fastest of the process's hardware queues.  HIP spreads a process's
- * streams over four hardware queues, and on MI355X these are not alike: every kernel of a frame differs by up to 1 us between them
- * (profiles/r03_bimodal_probe.txt; the occasional queue on which the normal-map pass took 1.5-3.5 us longer no longer
- * finds its victim: profiles/r03_xpass_trace.txt).  The call times `frames` serial frames (plus five untimed ones) on each of the context's first four
- * streams -- one per queue -- and re-orders its streams, fastest first: the serial path (the synchronous ocean_compute_waves) and pipeline
- * chain 0 then use the fastest queue, chains 1..3 the next ones.  us_per_frame (NULL or 4 floats) receives the measured frame times in
- * the new order.  50 frames tell the queues apart (4 x 55 frames: 14 ms at 2048^2, 4 ms at 512^2).  Afterwards the maps hold a calibration
- * frame (read-outs return OCEAN_E_NOT_READY until the next frame), and a stream handle fetched earlier with ocean_stream() may no longer be
- * the context's.  OCEAN_E_UNSUPPORTED with a caller-owned stream (ocean_set_stream) and with caller-bound or imported output (the
- * calibration frames must not land in memory somebody else owns).  Results of frames are unaffected: bit-identical.               */
-int ocean_select_streams(ocean_t* ctx, uint32_t frames, float* us_per_frame /* [4] or NULL */);
-/* Staggered start of a frame's launches (one 2048 x 2048 tile; ocean_kernels.h: start_ramp_wait): workgroup i of a launch whose grid is ONE
- * resident round waits i / G of a few microseconds before its first load, so that the early workgroups store while the late ones still load
- * (-5 % on a serial frame, -2.5 % on pipelined ones).  The library applies it only where every workgroup of the launch is resident at once on
- * THIS device (grid <= compute units x workgroups per unit); on != 0 (default) allows it, 0 switches it off for the context -- for a device
- * shared with other work, where a workgroup's wait is simply lost.  Frames are bit-identical either way.                                    */
-int ocean_set_start_ramp(ocean_t* ctx, int on);
-/* The x axis in ONE launch (round 5): frames of a single small tile run their height, normal-map and displacement workgroups as one grid --
- * the displacement workgroups transform at once and wait for the tile's height workgroups only before their stores -- two launches per frame
- * instead of three.  Applied where it was measured to pay (pipelined frames up to 512^2, which are bound by the rate of launches: 13-15 -> 8 us
- * per frame at depth 4; serial frames up to 128^2 only -- from 256^2 up the in-launch hand-off costs more than the kernel boundary it replaces)
- * and only where every workgroup of that grid is resident at once, one per compute unit; never in OCEAN_MODE_JACOBIAN.  on != 0 (default)
- * allows it, 0 keeps the three-launch frame.  Bit-identical either way; ocean_last_launch marks such a frame with OCEAN_LAUNCH_MERGED_X on
- * idx 1 and 2 (the same launch).  The same switch governs the step beyond it: pipelined frames of one tile up to 128^2 in the usual form run
- * as ONE launch (OCEAN_LAUNCH_ONE_LAUNCH; 64^2: 11.5 -> 3.9 us per frame at depth 4).                                                                                                          */
-int ocean_set_merged_xpass(ocean_t* ctx, int on);
-/* (Failure mode of those in-launch waits: a workgroup that has waited 20 ms for its producers gives up -- the device never hangs -- and sets a
- * host-coherent word; ocean_wait_frame, ocean_synchronize and every read-out then return OCEAN_E_HIP (ocean_last_hip_error:
- * hipErrorLaunchTimeOut) instead of handing out the frame, until the next ocean_prepare.  Never observed outside the fault-injection build.) */
-
-/* ---- introspection for tests and the bench -------------------------------- */
-/* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */
-int ocean_read_spectrum(ocean_t* ctx, uint32_t tile, float* h0, float* omega);
-/* Copies the generated gaussian draws of one tile (N*N*2).                      */
-int ocean_read_xi(ocean_t* ctx, uint32_t tile, float* xi);
-
-/* Times `frames` back-to-back asynchronous frames (t = t0 + j*dt) with HIP events after
- * `warmup` untimed ones, at the context's pipeline depth.  ms_total = whole timed region;
- * ms_kernel[3] = mean duration per kernel and frame, in ocean_kernel_name order (a kernel that the split frame order
- * launches twice reports the sum of its two launches), from events
- * bracketing every launch on its own stream during a second, separately timed run of
- * the same frames in the same regime (at depth > 1 the launches of different frames
- * overlap, so these are durations under that concurrency).  Any output pointer may be NULL. */
-int ocean_time_frames(ocean_t* ctx, float t0, float dt, int warmup, int frames,
-                      float* ms_total, float* ms_kernel /* [3] */);
-
-/* Name of the idx-th launch (0..2) of one frame, in the order ocean_time_frames reports
- * them: "k_zpass", "k_xpass_b", "k_xpass_disp" at every tile size.  NULL if idx is out of range. */
-const char* ocean_kernel_name(const ocean_t* ctx, int idx);
-
-/* What the most recent frame launched: the idx-th launch's (ocean_kernel_name order) tile size, grid, block and kernel
- * variant.  The host picks a kernel instantiation per frame from the tile size, the precisions, the mode, the pipeline
- * depth and the batch size (store policy, columns per z-pass workgroup, split last round); tests use this to prove that
- * every variant the launcher can select has met the oracle (tests/test_variants_gpu.py).                              */
-enum {
-    OCEAN_LAUNCH_NT_MAPS         = 1,    /* x passes: maps stored non-temporally (template flag NTS)                    */
-    OCEAN_LAUNCH_NT_INTER        = 2,    /* z pass: intermediates stored non-temporally (ZNT)                           */
-    OCEAN_LAUNCH_HALF_INTER      = 4,    /* half2 intermediates (Z16), all three                                        */
-    OCEAN_LAUNCH_JACOBIAN        = 8,    /* OCEAN_MODE_JACOBIAN: x passes' JAC instantiations, z pass's pair-3 branch   */
-    OCEAN_LAUNCH_FP16_SPECTRUM   = 16,   /* z pass reads the half2 copy of h0 (wave-uniform branch, no instantiation)   */
-    OCEAN_LAUNCH_FP32_DISPERSION = 32,   /* z pass reads the fp32 dispersion array: some multiple of the base frequency
-                                            needs more than 16 bits (wave-uniform branch)                               */
-    OCEAN_LAUNCH_SPLIT_LAST_ROUND = 64,  /* (rounds 2-3: the columns of a partially filled last round of z-pass workgroups split
-                                            over two workgroups each; never set since round 4 -- the single-transform form
-                                            replaced it -- the value stays reserved)                                    */
-    OCEAN_LAUNCH_SINGLE_TRANSFORM = 128, /* z pass: one transform per batch, half the threads (k_zpass_c1): two independent
-                                            workgroups per CU where the two-transform forms fit only one (4096^2)       */
-    OCEAN_LAUNCH_STAGGERED_START = 256,  /* not a variant (same instantiation, same bits): the launch's workgroups, all resident
-                                            at once, start spread over a few microseconds so that the early ones store while
-                                            the late ones still load -- the three launches of a frame of one 2048^2 tile
-                                            (serial and pipelined frames with ramps of their own), nowhere else          */
-    OCEAN_LAUNCH_SPLIT_ORDER     = 512,  /* developer builds only (never set by the shipped library): the frame ran in the split order of
-                                            profiles/r05_4096_experiments.txt -- z pass and k_xpass_b twice, each time half their work        */
-    OCEAN_LAUNCH_WT_INTER        = 2048, /* z pass: fp32 intermediates stored write-through (`sc1`: they leave the XCD's L2 as they are written, no
-                                            end-of-kernel write-back burst) -- serial frames at 1024^2 (batches) and 2048^2, single-transform form */
-    OCEAN_LAUNCH_ONE_LAUNCH      = 4096, /* the whole frame ran as ONE launch (k_frame: z-pass, height, normal-map and displacement workgroups in one
-                                            grid, one-way hand-offs inside it): pipelined frames of one tile up to 128^2 in the usual form; idx 0..2
-                                            then describe that one launch                                                                    */
-    OCEAN_LAUNCH_MERGED_X        = 1024  /* not a kernel variant: k_xpass_b ran the displacement workgroups as well (one launch for the whole x axis,
-                                            no k_xpass_disp); set on idx 1 and idx 2, which then describe that one launch                   */
-};
-typedef struct ocean_launch_info {
-    uint32_t tile_size;
-    uint32_t grid_x, grid_y, block;
-    uint32_t lds_bytes;
-    uint32_t flags;            /* OCEAN_LAUNCH_*                                                                         */
-    uint32_t per_workgroup;    /* z pass: spectrum columns per workgroup (1 or 2); x passes: map rows per workgroup     */
-    uint32_t mode;             /* OCEAN_MODE_* of the frame                                                              */
-} ocean_launch_info;
-int ocean_last_launch(const ocean_t* ctx, int idx, ocean_launch_info* out);
-
-/* HBM bytes per texel this pipeline has to move for one seven-field frame at the context's
- * precision settings (73 with the fp32 spectrum: 8 + 1 in -- the 16-bit dispersion is read for half of the columns, a
- * column and its point mirror share it --, 14 + 14 half-size intermediates out and in, 2 + 2 raw height, 32 maps).  SURVEY.md section 8d prices a plain 3.5-transform
- * two-pass scheme at 108; bench.py reports that figure separately, labelled as a model.     */
-int ocean_algorithmic_bytes_per_texel(const ocean_t* ctx);
-/* The same figure per launch (idx in ocean_kernel_name order; 23 / 28 / 22 for the fp32 seven-field frame): what
- * bench.py's roofline divides by a kernel's duration.  0 if idx is out of range.                                        */
-int ocean_algorithmic_bytes_per_launch(const ocean_t* ctx, int idx);
 
 #ifdef __cplusplus
 }

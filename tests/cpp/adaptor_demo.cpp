@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 
+#include "ocean_dev.h"          // (SelectFastestQueue below: the adaptor offers it only to hosts that include the developer header)
 #include "WSTessendorf.hpp"
 
 int main(int argc, char** argv)
@@ -44,8 +45,8 @@ int main(int argc, char** argv)
             const auto t0 = std::chrono::steady_clock::now();
             for (int j = 0; j < frames; ++j) model.ComputeWaves(t + 0.05f * (float)j);
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            std::fprintf(stderr, "adaptor_demo: N=%u ComputeWaves + read-out of both maps: %.1f us/frame\n",
-                         model.GetTileSize(), us / frames);
+            std::fprintf(stderr, "adaptor_demo: N=%u ComputeWaves + read-out of both maps: %.1f us/frame = %.1f GB/s over PCIe\n",
+                         n, us / frames, (double)(dispBytes + nrmBytes) * frames / us * 1e-3);
         }
         // optional fourth argument "async": the opt-in ComputeWavesAsync() / Wait() pair must deliver the same frame, keep the
         // previous one readable in between, and return A before the copy has landed.  Prints "async <ok> <us to A> <us to maps>".

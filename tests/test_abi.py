@@ -19,20 +19,43 @@ def abi():
     return _abi
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "ocean.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(ocean_[a-z0-9_]+)\s*\(", txt)))
+HEADERS = ("ocean.h", "ocean_consumers.h", "ocean_dev.h")
+
+
+def header_text(name=None):
+    names = HEADERS if name is None else (name,)
+    return "\n".join(re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", n)).read(), flags=re.S) for n in names)
+
+
+def declared_symbols(name=None):
+    return sorted(set(re.findall(r"\b(ocean_[a-z0-9_]+)\s*\(", header_text(name))))
 
 
 def test_header_and_binding_list_agree(abi):
     assert declared_symbols() == sorted(abi.SYMBOLS)
+    for name, symbols in abi.HEADERS.items():
+        assert declared_symbols(name) == sorted(symbols), name
+    assert len(abi.SYMBOLS) == len(set(abi.SYMBOLS))
+
+
+def test_the_boundary_header_keeps_the_survey_shape(abi):
+    """include/ocean.h is the SURVEY.md 8b shape -- lifetime, properties, Prepare, ComputeWaves, read-out, the gather --
+    and nothing of the bench / A-B plumbing, which lives in include/ocean_dev.h; at most 50 entry points."""
+    boundary = declared_symbols("ocean.h")
+    assert len(boundary) <= 50, len(boundary)
+    for dev in ("ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_select_streams", "ocean_set_start_ramp", "ocean_set_merged_xpass",
+                "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch", "ocean_read_spectrum", "ocean_read_xi"):
+        assert dev not in boundary and dev in declared_symbols("ocean_dev.h"), dev
+    for must in ("ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_prepare", "ocean_compute_waves", "ocean_read_maps",
+                 "ocean_device_maps", "ocean_get_heights", "ocean_gather_maps", "ocean_read_maps_staging", "ocean_export_maps"):
+        assert must in boundary, must
+    assert "OCEAN_LAUNCH_" not in header_text("ocean.h")            # the launch-variant flags are introspection: ocean_dev.h
 
 
 def test_header_enumerators_match_the_binding(abi):
     """Every OCEAN_* enumerator of include/ocean.h that the ctypes binding names has the header's value, and the binding names all of the
     launch flags, modes and error codes (a flag added on one side only -- OCEAN_LAUNCH_STAGGERED_START was the last one -- fails here)."""
-    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ocean.h")).read(), flags=re.S)
+    txt = header_text()
     enums = {k: int(v) for k, v in re.findall(r"\b(OCEAN_[A-Z0-9_]+)\s*=\s*(-?\d+)", txt)}
     assert len(enums) > 20
     for name, value in enums.items():
@@ -53,7 +76,7 @@ def test_library_exports_every_declared_symbol(abi):
 
 def test_abi_version_defaults_and_strerror(abi):
     L = abi.lib()
-    assert L.ocean_abi_version() == 4
+    assert L.ocean_abi_version() == 5
     p = abi.Params()
     L.ocean_default_params(C.byref(p))
     # WSTessendorf.h:36-43,181
@@ -235,7 +258,7 @@ def test_cpp_adaptor_has_reference_surface_and_links(abi, tmp_path):
 def test_abi_header_is_plain_c99(abi, tmp_path):
     """The boundary is a C ABI: include/ocean.h must compile as strict C99 and link from a C program."""
     src = tmp_path / "c_abi.c"
-    src.write_text('#include "ocean.h"\n#include <stdio.h>\n'
+    src.write_text('#include "ocean.h"\n#include "ocean_consumers.h"\n#include "ocean_dev.h"\n#include <stdio.h>\n'
                    'int main(void) { ocean_params p; ocean_t* h = 0; ocean_default_params(&p);\n'
                    '  if (ocean_abi_version() <= 0 || p.tile_length != 1000.0f) return 1;\n'
                    '  if (ocean_create(&h, 500, 1, 0) != OCEAN_E_INVALID) return 2;   /* not a power of two */\n'

@@ -528,3 +528,46 @@ def test_round5_switches_change_launches_and_no_bit():
     a3 = b.compute_waves(0.3)
     assert np.array_equal(a0, a1) and np.array_equal(a0, a2) and np.array_equal(a0, a3)
     b.close()
+
+
+@pytest.mark.parametrize("n,tiles,depth", [(64, 1, 1), (128, 1, 1), (512, 1, 1), (1024, 1, 1), (2048, 1, 1), (256, 3, 1), (512, 1, 3), (1024, 2, 2)])
+def test_compute_waves_read_is_compute_waves_plus_read_maps(n, tiles, depth):
+    """ocean_compute_waves_read (round 6): synthesis + both maps of every tile in host memory as ONE blocking call -- the reference's call
+    shape, WaterSurfaceMesh.cpp:145-154 + 701-755 -- with the normal map's copy started behind the frame's second launch.  Bit for bit what
+    ocean_compute_waves + ocean_read_maps deliver: small tiles (whose x axis is one launch: no such point in the frame, both copies follow
+    it), the reference's default 512^2, the headline 2048^2, batches, pipelined contexts; pageable and page-locked destinations; repeated
+    calls into the same arrays (a copy still in flight would show)."""
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi as A
+    b = W.OceanBatch(n, tiles, 0)
+    b.set_pipeline_depth(depth)
+    b.prepare(SEED + 21)
+    ref = []
+    for t in (0.0, 1.25, 7.5):
+        a = b.compute_waves(t)
+        ref.append((a.copy(), *[x.copy() for x in b.read_maps()]))
+    # pageable destinations, fresh arrays
+    for t, (a0, d0, q0) in zip((0.0, 1.25, 7.5), ref):
+        a, d, q = b.compute_waves_read(t)
+        assert np.array_equal(a, a0) and np.array_equal(d, d0) and np.array_equal(q, q0), t
+        assert b.heights(tiles - 1)[0] == a0[tiles - 1]
+    # page-locked destinations, the same two arrays every call (the adaptor's use)
+    d = np.zeros((tiles, n, n, 4), dtype=np.float32); q = np.zeros_like(d)
+    L = A.lib()
+    assert L.ocean_host_register(d.ctypes.data, d.nbytes) == 0 and L.ocean_host_register(q.ctypes.data, q.nbytes) == 0
+    try:
+        for rep in range(3):
+            for t, (a0, d0, q0) in zip((0.0, 1.25, 7.5), ref):
+                a, _, _ = b.compute_waves_read(t, d, q)
+                assert np.array_equal(a, a0) and np.array_equal(d, d0) and np.array_equal(q, q0), (rep, t)
+        # mixed with the other calls of the frame path
+        b.compute_waves_async(3.0); b.compute_waves_async(4.0)
+        a, _, _ = b.compute_waves_read(1.25, d, q)
+        assert np.array_equal(a, ref[1][0]) and np.array_equal(d, ref[1][1]) and np.array_equal(q, ref[1][2])
+        dd, qq = b.read_maps()
+        assert np.array_equal(dd, ref[1][1]) and np.array_equal(qq, ref[1][2])
+    finally:
+        L.ocean_host_unregister(d.ctypes.data); L.ocean_host_unregister(q.ctypes.data)
+    assert L.ocean_compute_waves_read(b._h, 0.0, None, None, q.ctypes.data) == A.OCEAN_E_INVALID
+    assert b.fault_recoveries == 0
+    b.close()

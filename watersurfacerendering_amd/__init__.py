@@ -100,6 +100,24 @@ class OceanBatch:
                    "ocean_compute_waves")
         return amp
 
+    def compute_waves_read(self, t: float, disp: np.ndarray | None = None, nrm: np.ndarray | None = None):
+        """ComputeWaves(t) and the read-out of every tile's maps as ONE blocking call (ocean_compute_waves_read: the normal map's copy
+        runs beside the displacement pass).  Returns (amplitudes, disp, nrm); disp / nrm [tiles, N, N, 4] float32 are allocated unless
+        passed in (pass page-locked arrays -- host_register -- for true DMAs)."""
+        n = self.tile_size
+        amp = np.empty(self.tiles, dtype=np.float32)
+        d = np.empty((self.tiles, n, n, 4), dtype=np.float32) if disp is None else disp
+        q = np.empty((self.tiles, n, n, 4), dtype=np.float32) if nrm is None else nrm
+        assert d.dtype == np.float32 and q.dtype == np.float32 and d.size == q.size == self.tiles * n * n * 4 and d.flags.c_contiguous and q.flags.c_contiguous
+        _abi.check(self._L.ocean_compute_waves_read(self._h, t, amp.ctypes.data_as(C.POINTER(C.c_float)), d.ctypes.data_as(C.c_void_p),
+                                                    q.ctypes.data_as(C.c_void_p)), "ocean_compute_waves_read")
+        return amp, d, q
+
+    @property
+    def fault_recoveries(self) -> int:
+        """How often the host re-ran frames because an in-launch wait had given up (ocean_fault_recoveries; 0 on a dedicated device)."""
+        return int(self._L.ocean_fault_recoveries(self._h))
+
     def compute_waves_async(self, t: float):
         _abi.check(self._L.ocean_compute_waves_async(self._h, t), "ocean_compute_waves_async")
 

@@ -27,20 +27,27 @@ OCEAN_COMM_ID_BYTES = 128
 OCEAN_ALL_TILES = 0xFFFFFFFF
 OCEAN_MODE_FULL7, OCEAN_MODE_CHOPPY5, OCEAN_MODE_HEIGHT1, OCEAN_MODE_JACOBIAN = 0, 1, 2, 3
 
-#: every symbol include/ocean.h declares (tests check the .so exports each one)
-SYMBOLS = [
-    "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_build_id", "ocean_last_hip_error",
+#: every symbol the library's three headers declare (tests check the .so exports each one, and that each list equals its header's)
+SYMBOLS_BOUNDARY = [        # include/ocean.h: the drop-in boundary
+    "ocean_default_params", "ocean_strerror", "ocean_abi_version", "ocean_build_id", "ocean_last_hip_error", "ocean_fault_recoveries",
     "ocean_create", "ocean_destroy", "ocean_set_params", "ocean_get_params", "ocean_set_lambda",
     "ocean_set_tile_size", "ocean_tile_size", "ocean_tiles", "ocean_prepare",
     "ocean_compute_waves", "ocean_compute_waves_async", "ocean_wait_frame", "ocean_set_frame_tracking", "ocean_set_time_offsets", "ocean_synchronize",
-    "ocean_get_heights", "ocean_read_maps", "ocean_host_register", "ocean_host_unregister",
+    "ocean_get_heights", "ocean_read_maps", "ocean_compute_waves_read", "ocean_host_register", "ocean_host_unregister",
     "ocean_read_maps_async", "ocean_staging_map_offset", "ocean_read_maps_staging", "ocean_device_maps", "ocean_set_external_readers", "ocean_export_maps", "ocean_bind_output", "ocean_bind_output_dmabuf",
     "ocean_comm_unique_id", "ocean_comm_init", "ocean_comm_destroy", "ocean_comm_count", "ocean_gather_maps", "ocean_gather_maps_f16", "ocean_last_rccl_error",
+    "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream",
+]
+SYMBOLS_CONSUMERS = [       # include/ocean_consumers.h: SURVEY.md 8f ranks 3-4
     "ocean_displace_grid", "ocean_displace_grid_cascades", "ocean_read_grid", "ocean_device_grid",
     "ocean_mip_texels", "ocean_build_mips", "ocean_read_mips", "ocean_device_mips",
-    "ocean_set_mode", "ocean_set_dispersion", "ocean_set_spectrum_precision", "ocean_set_intermediate_precision", "ocean_set_pipeline_depth", "ocean_stream", "ocean_set_stream", "ocean_read_spectrum", "ocean_read_xi",
+]
+SYMBOLS_DEV = [             # include/ocean_dev.h: tests, bench.py, tools/
+    "ocean_read_spectrum", "ocean_read_xi",
     "ocean_select_streams", "ocean_set_start_ramp", "ocean_set_merged_xpass", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
 ]
+SYMBOLS = SYMBOLS_BOUNDARY + SYMBOLS_CONSUMERS + SYMBOLS_DEV
+HEADERS = {"ocean.h": SYMBOLS_BOUNDARY, "ocean_consumers.h": SYMBOLS_CONSUMERS, "ocean_dev.h": SYMBOLS_DEV}
 
 OCEAN_LAUNCH_NT_MAPS, OCEAN_LAUNCH_NT_INTER, OCEAN_LAUNCH_HALF_INTER, OCEAN_LAUNCH_JACOBIAN = 1, 2, 4, 8
 OCEAN_LAUNCH_FP16_SPECTRUM, OCEAN_LAUNCH_FP32_DISPERSION, OCEAN_LAUNCH_SPLIT_LAST_ROUND, OCEAN_LAUNCH_SINGLE_TRANSFORM = 16, 32, 64, 128
@@ -77,13 +84,14 @@ _ID_MARK = b"OCEAN_BUILD_ID:"
 
 def source_build_id(defs: str = "") -> str:
     """Content hash of the library's sources, computed exactly as csrc/Makefile does (BUILD_ID): SHA-256 over Makefile, *.h, *.hip of
-    csrc/ in byte order of their names, then include/ocean.h, then the build's extra definitions; first 16 hex digits."""
+    csrc/ in byte order of their names, then include/ocean.h, ocean_consumers.h, ocean_dev.h, then the build's extra definitions; first 16 hex digits."""
     import hashlib
     h = hashlib.sha256()
     names = sorted(f for f in os.listdir(CSRC) if f == "Makefile" or (f.endswith((".h", ".hip")) and os.path.isfile(os.path.join(CSRC, f))))
     for f in names:
         h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(open(os.path.join(os.path.dirname(_PKG), "include", "ocean.h"), "rb").read())
+    for f in ("ocean.h", "ocean_consumers.h", "ocean_dev.h"):
+        h.update(open(os.path.join(os.path.dirname(_PKG), "include", f), "rb").read())
     h.update(defs.encode())
     return h.hexdigest()[:16]
 
@@ -155,6 +163,8 @@ def lib() -> C.CDLL:
         "ocean_abi_version": (i32, []),
         "ocean_build_id": (C.c_char_p, []),
         "ocean_last_hip_error": (i32, []),
+        "ocean_fault_recoveries": (C.c_uint, [P]),
+        "ocean_compute_waves_read": (i32, [P, f32, FP, P, P]),
         "ocean_create": (i32, [C.POINTER(P), u32, u32, i32]),
         "ocean_destroy": (None, [P]),
         "ocean_set_params": (i32, [P, u32, C.POINTER(Params)]),

@@ -55,12 +55,22 @@ typedef float v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2 tov(c32 a) { return (v2){a.x, a.y}; }
 __device__ __forceinline__ c32 toc(v2 a) { return make_float2(a.x, a.y); }
 
+// (ONE asm statement for the pair: between two statements the compiler's hazard recogniser, which must assume that an inline-asm result may
+//  carry a destination-select forwarding hazard, put an s_nop in front of the dependent second instruction -- 144 of them per wave and z-pass
+//  column, 4 issue cycles each, for a hazard that full-register packed-fp32 results do not have; round 6, profiles/r06_zpass_experiments.txt)
 __device__ __forceinline__ v2 pk_cmul(v2 a, v2 w)           // a * w
 {
-    v2 t, d;
+    v2 d;
+#ifdef OCEAN_CMUL_SPLIT      // developer A/B: the two-statement form of rounds 2-5
+    v2 t;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));          // (a.x w.x, a.x w.y)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                 // (t.x - a.y w.y, t.y + a.y w.x)
         : "=v"(d) : "v"(a), "v"(w), "v"(t));
+#else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                   // (a.x w.x, a.x w.y)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                 // (t.x - a.y w.y, t.y + a.y w.x)
+        : "=&v"(d) : "v"(a), "v"(w));
+#endif
     return d;
 }
 __device__ __forceinline__ v2 pk_add_i(v2 b, v2 a)          // b + i a = (b.x - a.y, b.y + a.x)

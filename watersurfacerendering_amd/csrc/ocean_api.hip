@@ -57,7 +57,7 @@ static void free_set(ocean_ctx* c, int i)
     if (c->done_rec[i]) (void)hipHostFree(c->done_rec[i]);
     for (auto& p : c->pack_half[i]) if (p) { (void)hipFree(p); p = nullptr; }
     c->z[i] = nullptr; c->zh[i] = nullptr; c->hraw[i] = nullptr; c->z3[i] = nullptr; c->jraw[i] = nullptr; c->jac0[i] = nullptr;
-    c->minmax[i] = nullptr; c->hdone[i] = nullptr; c->zdone[i] = nullptr; c->zgen[i] = 0; c->done_ctr[i] = nullptr; c->done_rec[i] = nullptr; c->seq[i] = 0;
+    c->minmax[i] = nullptr; c->hdone[i] = nullptr; c->zdone[i] = nullptr; c->zgen[i] = 0; c->done_ctr[i] = nullptr; c->done_rec[i] = nullptr; c->seq[i] = 0; c->frame_valid[i] = false;
     c->dispN[i] = nullptr; c->nrmN[i] = nullptr;
 }
 
@@ -85,7 +85,7 @@ static int alloc_set_buffers(ocean_ctx* c, int i)
     // buffer: the synchronous ComputeWaves polls it -- no stream synchronisation, no device-to-host copy
     HIP_TRY(hipHostMalloc((void**)&c->done_rec[i], t * sizeof(uint4), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->done_rec[i], 0, t * sizeof(uint4));
-    c->seq[i] = 0;
+    c->seq[i] = 0; c->frame_valid[i] = false;       // (a fresh, zeroed record buffer: numbering may start over)
     // both maps of the set in ONE allocation [displacement | normal] -- the range ocean_export_maps hands out as one dma-buf,
     // in the order the reference lays its staging buffer out (WaterSurfaceMesh.cpp:736-738); a whole number of 2 MiB pages
     c->maps_bytes[i] = (2 * t * n2 * sizeof(float4) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
@@ -155,23 +155,59 @@ static int alloc_device(ocean_ctx* c)
     return OCEAN_OK;
 }
 
-// An in-launch wait of a merged / one-launch frame that gave up (ocean_kernels.h: wait_counter) has produced a wrong frame: never silently.
-static int check_fault(ocean_ctx* c)
+// An in-launch wait of a merged / one-launch frame that gave up (ocean_kernels.h: wait_counter) has produced a wrong frame: never silently -- and
+// never fatally either (on a shared or time-sliced device a preempted producer is a slow producer, not a broken one).  The host
+// drains the context, clears the word, switches the hand-off forms OFF for this context (launch_frame: c->merged_x) and runs the most recent frame
+// of every chain that used one again in the three-launch form -- same time, same chain, same tracking --, so the caller's wait / synchronise /
+// read-out returns the frame it asked for.  What cannot be redone is reported once: a stream-ordered consumer (gather, vertex stage, mips)
+// enqueued behind such a frame has consumed it (OCEAN_E_HIP / hipErrorLaunchTimeOut from this call; the context is usable, the consumer call is
+// the caller's to repeat).
+static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks, bool track, int redo_set);
+static bool fault_raised(const ocean_ctx* c) { return c->fault && __atomic_load_n(c->fault, __ATOMIC_ACQUIRE) != 0u; }
+static void reset_pipeline_state(ocean_ctx* c)
 {
-    if (c->fault && __atomic_load_n(c->fault, __ATOMIC_ACQUIRE) != 0u) { g_last_hip = (int)hipErrorLaunchTimeOut; return OCEAN_E_HIP; }
-    return OCEAN_OK;
+    for (bool& p : c->gather_pending) p = false;
+    c->consumer_pending = false;
+    c->burst_pos = 0; c->z_last_set = -1;          // the pipeline is empty: the next pipelined frames start staggered (enqueue_frame)
 }
-
-static int sync_all(ocean_ctx* c)
+static int drain_streams(ocean_ctx* c)
 {
     for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) HIP_TRY(hipStreamSynchronize(c->own[i]));
     if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
     if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
-    { int rc_ = check_fault(c); if (rc_) return rc_; }
-    for (bool& p : c->gather_pending) p = false;
-    c->consumer_pending = false;
-    c->burst_pos = 0; c->z_last_set = -1;          // the pipeline is empty: the next pipelined frames start staggered (enqueue_frame)
+    return OCEAN_OK;
+}
+static int recover_fault(ocean_ctx* c)
+{
+    if (c->recovering) { g_last_hip = (int)hipErrorLaunchTimeOut; return OCEAN_E_HIP; }
+    { int rc_ = drain_streams(c); if (rc_) return rc_; }
+    bool consumed = c->consumer_pending;
+    for (bool p : c->gather_pending) consumed = consumed || p;
+    __atomic_store_n(c->fault, 0u, __ATOMIC_RELEASE);
+    c->merged_x = false;                            // this context keeps the three-launch frame from now on (ocean_set_merged_xpass(ctx, 1) allows the forms again)
+    c->fault_recoveries++;
+    reset_pipeline_state(c);
+    c->recovering = true;
+    int rc = OCEAN_OK;
+    const int last = c->last_set;
+    for (int set = 0; set < MAXD && rc == OCEAN_OK; ++set)
+        if (c->frame_valid[set] && c->last_handoff[set]) rc = enqueue_frame(c, c->last_t[set], c->last_pipe[set], nullptr, c->tracked[set], set);
+    c->last_set = last;                             // the caller's "most recent frame" is still the one it enqueued last
+    if (rc == OCEAN_OK) rc = drain_streams(c);
+    c->recovering = false;
+    reset_pipeline_state(c);
+    if (rc) return rc;
+    if (fault_raised(c) || consumed) { g_last_hip = (int)hipErrorLaunchTimeOut; return OCEAN_E_HIP; }
+    return OCEAN_OK;
+}
+static int check_fault(ocean_ctx* c) { return fault_raised(c) ? recover_fault(c) : OCEAN_OK; }
+
+static int sync_all(ocean_ctx* c)
+{
+    { int rc_ = drain_streams(c); if (rc_) return rc_; }
+    if (fault_raised(c)) return recover_fault(c);   // (resets the pipeline bookkeeping whatever it returns)
+    reset_pipeline_state(c);
     return OCEAN_OK;
 }
 #define SYNC_ALL(c) do { int rc_ = sync_all(c); if (rc_) return rc_; } while (0)
@@ -215,6 +251,7 @@ int ocean_abi_version(void) { return OCEAN_ABI_VERSION; }
 static const char g_build_id[] = "OCEAN_BUILD_ID:" OCEAN_BUILD_ID;
 const char* ocean_build_id(void) { return g_build_id + 15; }
 int ocean_last_hip_error(void) { return g_last_hip; }
+unsigned ocean_fault_recoveries(const ocean_t* c) { return c ? c->fault_recoveries : 0u; }
 
 int ocean_create(ocean_t** out, uint32_t tile_size, uint32_t tiles, int device)
 {
@@ -342,10 +379,13 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
 {
     if (!c) return OCEAN_E_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    // a fault an in-launch wait reported (check_fault) is sticky until the next Prepare: drain what is in flight, then start clean
+    // drain what is in flight, then start clean: no frame of the old spectrum is recovered (check_fault), the pipeline bookkeeping is empty
     for (int i = 0; i < MAXD; ++i) if (c->own[i]) (void)hipStreamSynchronize(c->own[i]);
     if (c->user) (void)hipStreamSynchronize(c->user);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->fault) *c->fault = 0u;
+    reset_pipeline_state(c);
+    for (bool& v : c->frame_valid) v = false;
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     std::vector<TileParams> tp(t);
     for (size_t i = 0; i < t; ++i) {
@@ -469,21 +509,24 @@ static const char* kernel_name_of(int idx)
     return nullptr;
 }
 
-// Enqueues one frame.  pipelined = the call may use the pipeline chains (depth > 1).
-static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks, bool track = false)
+// Enqueues one frame.  pipelined = the call may use the pipeline chains (depth > 1).  redo_set >= 0: recover_fault runs chain redo_set's most
+// recent frame again (same chain and regime; no burst / rotation bookkeeping, no hand-off form: c->merged_x is off by then).
+static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks, bool track = false, int redo_set = -1)
 {
     if (!c) return OCEAN_E_INVALID;
     if (!c->prepared) return OCEAN_E_NOT_READY;
+    (void)hipGetLastError();        // an earlier, unrelated error of this thread must not be taken for this frame's (launch_frame ends in hipGetLastError)
+    const bool redo = redo_set >= 0;
     // depth D: frames f, f+1, ... run as D independent chains (own stream, own
     // intermediates, own map set) with no cross-stream dependency at all -- the first
     // pass of one frame fills the memory-idle phases of the others' map passes.
     // Caller-bound output buffers or a caller stream force depth 1.
     const bool pipe = pipelined && c->depth > 1 && !c->user && !c->ext_disp && !c->ext_nrm;
-    if (!pipe && c->depth > 1 && pipelined) {           // leaving pipelined mode: drain the other chains first
+    if (!pipe && c->depth > 1 && pipelined && !redo) {  // leaving pipelined mode: drain the other chains first
         int rc_ = sync_all(c);
         if (rc_) return rc_;
     }
-    const int set = pipe ? (int)(c->frame_ctr % (uint64_t)c->depth) : 0;
+    const int set = redo ? redo_set : (pipe ? (int)(c->frame_ctr % (uint64_t)c->depth) : 0);
     {
         int rc_ = alloc_set(c, set);
         if (rc_) return rc_;
@@ -506,10 +549,13 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.zdone = c->zdone[set]; a.zdone_target = 0; a.poll_sleep = 0; a.fault = c->fault; c->cur_set = set;
     a.z3 = c->z3[set]; a.jraw = c->jraw[set]; a.jac0 = c->jac0[set];
     a.done_rec = c->done_rec[set]; a.done_ctr = track ? c->done_ctr[set] : nullptr;
-    // the chain's sequence number, tracking and burst state are committed only once the launches have succeeded; a failed enqueue
-    // invalidates the chain's frame (see below: part of its launches may have run)
+    // The chain's sequence number is committed at once and never reused while the record buffer lives (a frame whose enqueue fails half way
+    // must not leave its number to the next one: a stale completion record would match it); tracking and burst state are committed only once
+    // the launches have succeeded, and a failed enqueue invalidates the chain's frame (see below: part of its launches may have run).
     unsigned frame_seq = c->seq[set] + 1u;
     if (frame_seq == 0) frame_seq = 1;                  // never 0: a fresh record buffer reads as "no frame"
+    c->seq[set] = frame_seq;
+    c->frame_valid[set] = false;
     a.frame_seq = frame_seq;
     a.disp = c->ext_disp ? c->ext_disp : c->dispN[set];
     a.nrm = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
@@ -572,7 +618,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     // (the burst state -- burst_pos, z_last_set -- is committed below, once the launches have succeeded; the stream wait enqueued here is
     //  harmless if they do not: a wait for an event that has been recorded already)
     c->after_z = nullptr;
-    const bool stagger = pipe && c->burst_pos < c->depth;
+    const bool stagger = pipe && !redo && c->burst_pos < c->depth;
     if (stagger) {
         if (!c->z_done[set]) HIP_TRY(hipEventCreateWithFlags(&c->z_done[set], hipEventDisableTiming));
         if (c->z_last_set >= 0 && c->z_last_set != set && c->z_done[c->z_last_set]) HIP_TRY(hipStreamWaitEvent(st, c->z_done[c->z_last_set], 0));
@@ -589,19 +635,19 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         // some of the frame's launches may have run: the chain's records, height keys and maps no longer describe ONE frame -- the chain has
         // no frame until the next successful enqueue (wait / read-out: OCEAN_E_NOT_READY), the other chains are untouched
         g_last_hip = (int)e;
-        c->seq[set] = 0;
         if (c->last_set == set) c->have_frame = false;
         c->zgen[set] = 0;                                   // (a one-launch frame may have counted itself without running: start over)
         (void)hipMemsetAsync(c->zdone[set], 0, c->tiles * sizeof(unsigned), st);
         return OCEAN_E_HIP;
     }
-    if (pipe) {
+    if (pipe && !redo) {
         if (stagger) c->z_last_set = set;
         if (c->burst_pos < MAXD + 1) c->burst_pos++;
     }
-    c->seq[set] = frame_seq;
+    c->frame_valid[set] = true;
     c->tracked[set] = track;
-    if (pipe) c->frame_ctr++;
+    c->last_t[set] = t; c->last_pipe[set] = pipelined; c->last_handoff[set] = c->handoff;
+    if (pipe && !redo) c->frame_ctr++;
     c->have_frame = true;
     c->last_set = set;
     return OCEAN_OK;
@@ -636,7 +682,8 @@ int ocean_synchronize(ocean_t* c)
 // (ocean_kernels.h: frame_done), then -- the device is busy with something long, or shared -- a stream synchronisation.
 static int wait_frame(ocean_ctx* c, int set)
 {
-    if (!c->have_frame || !c->done_rec[set] || c->seq[set] == 0) return OCEAN_E_NOT_READY;
+    if (!c->have_frame || !c->done_rec[set] || !c->frame_valid[set]) return OCEAN_E_NOT_READY;
+    for (int attempt = 0; ; ++attempt) {
     const unsigned want = c->seq[set];
     const volatile uint4* rec = c->done_rec[set];
     bool synced = false;
@@ -669,7 +716,13 @@ static int wait_frame(ocean_ctx* c, int set)
         c->h_minmax[2 * i + 0] = rec[i].x;
         c->h_minmax[2 * i + 1] = rec[i].y;
     }
-    return check_fault(c);
+    if (!fault_raised(c) || attempt > 0) break;
+    // an in-launch wait of some frame of this context gave up: recover (this chain's frame is run again if it was one of them -- new
+    // sequence number, everything drained) and read the records once more
+    { int rc_ = recover_fault(c); if (rc_) return rc_; }
+    if (!c->frame_valid[set]) return OCEAN_E_NOT_READY;
+    }
+    return fault_raised(c) ? OCEAN_E_HIP : OCEAN_OK;
 }
 
 static float amp_of(const ocean_ctx* c, uint32_t tile, float* mn_out, float* mx_out)
@@ -737,6 +790,62 @@ int ocean_read_maps(ocean_t* c, uint32_t first, uint32_t count, float* disp, flo
     SYNC_ALL(c);
     if (disp) HIP_TRY(hipMemcpy(disp, d, count * n2 * sizeof(float4), hipMemcpyDeviceToHost));
     if (nrm) HIP_TRY(hipMemcpy(nrm, q, count * n2 * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+// ComputeWaves + read-out as ONE blocking call (the reference's call shape: WaterSurfaceMesh.cpp:145-154 calls ComputeWaves, :701-755 copies both
+// maps).  The normal map is final behind the frame's second launch: its copy starts there, on a copy stream, and runs beside the displacement
+// pass; the displacement map's copy follows its kernel on the frame's stream.  The call returns from a poll of the two copies' events.
+int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, float* nrm)
+{
+    if (!c || !disp || !nrm) return OCEAN_E_INVALID;
+    if (!c->prepared) return OCEAN_E_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->nrm_final) HIP_TRY(hipEventCreateWithFlags(&c->nrm_final, hipEventDisableTiming));
+    for (auto& ev : c->copy_done) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->after_b = c->nrm_final; c->after_b_recorded = false;
+    int rc = enqueue_frame(c, t, true, nullptr, true);
+    c->after_b = nullptr;
+    if (rc) return rc;
+    const int set = c->last_set;
+    hipStream_t st = stream_of(c, set);
+    const size_t bytes = (size_t)c->tiles * c->n * c->n * sizeof(float4);
+    const float4* d = c->ext_disp ? c->ext_disp : c->dispN[set];
+    const float4* q = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
+    hipStream_t nst = st;
+    if (c->after_b_recorded) {      // (frames whose x axis is one launch -- small tiles -- have no such point: both copies follow the frame)
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->nrm_final, 0));
+        nst = c->copy_stream;
+    }
+    HIP_TRY(hipMemcpyAsync(nrm, q, bytes, hipMemcpyDeviceToHost, nst));
+    HIP_TRY(hipEventRecord(c->copy_done[0], nst));
+    HIP_TRY(hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(c->copy_done[1], st));
+    rc = wait_frame(c, set);        // the frame's completion records (a poll): A, min, max -- the copies are still in flight
+    if (rc == OCEAN_OK && c->fault_recoveries_seen != c->fault_recoveries) {
+        // the frame was run again (an in-launch wait had given up): what the copies took may be the wrong frame's -- copy again, plainly
+        c->fault_recoveries_seen = c->fault_recoveries;
+        HIP_TRY(hipStreamSynchronize(nst)); HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(nrm, q, bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(disp, d, bytes, hipMemcpyDeviceToHost));
+    }
+    // the copies: polled like the records (a blocking synchronisation's wake-up costs 13-16 us per call), then -- long copies -- waited for
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    for (int k = 0; k < 2; ++k) {
+        unsigned spins = 0;
+        for (;;) {
+            const hipError_t e = hipEventQuery(c->copy_done[k]);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) { g_last_hip = (int)e; return OCEAN_E_HIP; }
+            if ((++spins & 63u) == 0 && clock::now() - t0 > std::chrono::milliseconds(1)) { HIP_TRY(hipEventSynchronize(c->copy_done[k])); break; }
+            __builtin_ia32_pause();
+        }
+    }
+    if (rc) return rc;
+    if (out_amp)
+        for (uint32_t i = 0; i < c->tiles; ++i) out_amp[i] = amp_of(c, i, nullptr, nullptr);
     return OCEAN_OK;
 }
 
@@ -882,6 +991,9 @@ int ocean_bind_output_dmabuf(ocean_t* c, int dmabuf_fd, size_t bytes, size_t dis
 // its stream wait for the previous consumer launch, so that two of them never write those buffers at once.
 static int consumer_begin(ocean_ctx* c, hipStream_t st)
 {
+    // (a frame whose in-launch wait has given up by now is recovered before anything consumes it; one that gives up later is reported
+    //  by the next wait / synchronisation: recover_fault)
+    { int rc_ = check_fault(c); if (rc_) return rc_; }
     if (c->consumer_pending && c->consumer_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->consumer_ev, 0));
     return OCEAN_OK;
 }
@@ -1277,6 +1389,26 @@ extern "C" int ocean_debug_xb_trace(ocean_t* c, int enable, unsigned long long* 
     return OCEAN_OK;
 }
 #endif
+#ifdef OCEAN_CLOCKPROBE
+// diagnostic build only (tools/slow_window.py): enable = allocate the probe buffer (the next single-transform z passes fill it, record
+// [frame_seq % 4096][workgroup][4]); host_out = copy `count` 64-bit words out, starting at word `first`
+extern "C" int ocean_debug_clockprobe(ocean_t* c, int enable, unsigned long long* host_out, size_t first, size_t count)
+{
+    if (!c) return OCEAN_E_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    SYNC_ALL(c);
+    const size_t bytes = (size_t)ocean::CLOCKPROBE_LAUNCHES * ocean::CLOCKPROBE_WGS * 4 * sizeof(unsigned long long);
+    if (enable && !c->stamps) {
+        HIP_TRY(hipMalloc(&c->stamps, bytes));
+        HIP_TRY(hipMemset(c->stamps, 0, bytes));
+    }
+    if (host_out) {
+        if (!c->stamps || (first + count) * sizeof(unsigned long long) > bytes) return OCEAN_E_INVALID;
+        HIP_TRY(hipMemcpy(host_out, c->stamps + first, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    return OCEAN_OK;
+}
+#endif
 #ifdef OCEAN_STAMPS
 // diagnostic build only: per-workgroup clock stamps of the last frame
 int ocean_debug_stamps(ocean_t* c, int enable, unsigned long long* host_out, size_t count)
@@ -1467,6 +1599,7 @@ static int gather_impl(ocean_ctx* c, int root, void* d_recv_disp, void* d_recv_n
     if (c->comm_rank == root && (!d_recv_disp || !d_recv_nrm)) return OCEAN_E_INVALID;
     if (!c->prepared || !c->have_frame) return OCEAN_E_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
+    { int rc_ = check_fault(c); if (rc_) return rc_; }                        // (as in consumer_begin)
     const int set = c->last_set;
     const size_t texels = (size_t)c->tiles * c->n * c->n;
     const size_t count = texels * 4;                                          // elements per map array per rank

@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/ocean.h"
+#include "../../include/ocean_consumers.h"
+#include "../../include/ocean_dev.h"
 #include "ocean_kernels.h"
 
 constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
@@ -67,7 +69,16 @@ struct ocean_ctx {
     bool tracked[MAXD] = {};        // the chain's most recent frame counts its finished workgroups (completion records written LAST:
                                     //   ocean_wait_frame polls); otherwise the records only carry the height keys and the wait is a stream synchronisation
     bool track_async = false;       // ocean_set_frame_tracking: asynchronous frames are tracked too (the synchronous call always is)
-    unsigned seq[MAXD] = {};        // sequence number of the chain's most recently enqueued frame (0: none since the buffers exist)
+    unsigned seq[MAXD] = {};        // sequence number of the chain's most recently ISSUED frame: monotonic while the chain's record buffer lives, committed even
+                                    //   when the enqueue failed half way (a reused number could match a stale completion record: ADVICE r05)
+    bool frame_valid[MAXD] = {};    // the chain's most recent enqueue succeeded: its records, keys and maps describe ONE frame
+    float last_t[MAXD] = {};        // time, regime (pipelined or not) and form of the chain's most recent frame: what recover_fault (ocean_api.hip) needs to
+    bool last_pipe[MAXD] = {};      //   run it again
+    bool last_handoff[MAXD] = {};   // ... it used an in-launch hand-off (merged x pass / one-launch frame: the only forms whose waits can give up)
+    bool handoff = false;           // set by launch_frame: the frame it has just enqueued uses an in-launch hand-off
+    bool recovering = false;        // recover_fault is re-enqueueing (no recursion)
+    unsigned fault_recoveries = 0;  // recoveries after an in-launch wait gave up (ocean_fault_recoveries)
+    unsigned fault_recoveries_seen = 0;   // ... that ocean_compute_waves_read has accounted for
     float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use): ONE allocation per set,
     float4* nrmN[MAXD] = {};       //   [displacement maps of all tiles | normal maps of all tiles] (nrmN points into dispN's)
     size_t maps_bytes[MAXD] = {};  // size of that allocation (a whole number of 2 MiB pages: ocean_export_maps)
@@ -93,7 +104,7 @@ struct ocean_ctx {
     float* h0_inv_scale = nullptr;
     unsigned* h0_maxbits = nullptr;
     unsigned* h_minmax = nullptr;  // pinned
-    unsigned* fault = nullptr;     // host-coherent word the kernels' in-launch waits set when they give up (FrameArgs::fault); sticky until ocean_prepare
+    unsigned* fault = nullptr;     // host-coherent word the kernels' in-launch waits set when they give up (FrameArgs::fault); cleared by recover_fault
     float4* grid_pos = nullptr;     // vertex-stage consumer output (ocean_displace_grid)
     float4* grid_nrm = nullptr;
     uint32_t grid_vertices = 0, grid_capacity = 0;
@@ -110,6 +121,10 @@ struct ocean_ctx {
     ocean_launch_info last_launch[3] = {};  // what the most recent frame launched (ocean_last_launch)
     hipEvent_t z_done[MAXD] = {};       // pipelined frames right after a drain: recorded behind a chain's z pass (see enqueue_frame)
     hipEvent_t after_z = nullptr;       // what launch_frame records behind the z pass of the frame being enqueued (null: nothing)
+    hipEvent_t after_b = nullptr;       // ... and behind k_xpass_b, where the frame has a displacement pass of its own behind it (ocean_compute_waves_read)
+    bool after_b_recorded = false;
+    hipStream_t copy_stream = nullptr;  // ocean_compute_waves_read: the normal map's device-to-host copy runs here, beside the displacement pass
+    hipEvent_t nrm_final = nullptr, copy_done[2] = {};   // its events: normal map final / the two copies have landed
     int burst_pos = 0;                  // pipelined frames enqueued since the context's streams were last drained
     int z_last_set = -1;
     hipEvent_t consumer_ev = nullptr;   // behind the most recent consumer launch (mips, grid): the context-wide output buffers of

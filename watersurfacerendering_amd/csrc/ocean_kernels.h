@@ -1226,6 +1226,39 @@ __device__ __forceinline__ void start_ramp_wait(int ramp, unsigned idx, unsigned
     }
 }
 
+#ifdef OCEAN_CLOCKPROBE
+// diagnostic build only (tools/slow_window.py, profiles/r06_slow_window.txt): what clock did a launch of the single-transform z pass run at?
+// Thread 0 of every workgroup reads the shader-clock counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
+// (s_memrealtime) when the workgroup starts and when its last store has been issued; record [launch % LAUNCHES][workgroup][4] =
+// {start, end (100 MHz ticks), shader cycles in between, XCC id | HW id << 32}.  The in-kernel clock of the launch is the median over its
+// workgroups of cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS give-back (6)); its duration max(end) - min(start).  No output value
+// depends on a stamp; the shipped library has none of this.
+static __device__ unsigned long long* g_clockprobe = nullptr;
+constexpr unsigned CLOCKPROBE_LAUNCHES = 4096, CLOCKPROBE_WGS = 1032;
+struct ClockProbe {
+    unsigned long long* p;
+    unsigned long long c0, r0;
+    __device__ explicit ClockProbe(unsigned launch) : p(nullptr), c0(0), r0(0)
+    {
+        if (threadIdx.x == 0 && g_clockprobe && blockIdx.y == 0 && blockIdx.x < CLOCKPROBE_WGS) {
+            p = g_clockprobe + 4 * ((size_t)(launch % CLOCKPROBE_LAUNCHES) * CLOCKPROBE_WGS + blockIdx.x);
+            c0 = __builtin_amdgcn_s_memtime();
+            r0 = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    __device__ void end()
+    {
+        if (p) {
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p[0] = r0; p[1] = r1; p[2] = c1 - c0; p[3] = (unsigned long long)xcc | ((unsigned long long)hwid << 32);
+        }
+    }
+};
+#endif
+
 // ============================================================================
 // k_zpass_c1: the z pass with ONE transform per batch (four batches per column: pair 0, pair 1, pair 2, height) and half the threads.
 // For 4096^2: the two-transform forms need 102-119 KB of LDS (70 KB of FFT image + the S+ / kz tables) -- ONE 1024-thread workgroup per
@@ -1332,8 +1365,10 @@ template <int N> constexpr size_t zpass_c1_lds_bytes() { return sizeof(c32) * ff
 
 // (the instantiations that carry all four forms of the spectrum -- !FAST: fp16 copy, fp32 dispersion -- need a few registers more than the
 //  80 of six waves per SIMD and spilled 24-28 bytes per lane under that cap: they ask for five, 96 registers, no scratch)
+// (a radix-16 plan -- N / 16 threads, two waves per 2048-point workgroup -- may use the registers of three waves per SIMD: six workgroups per CU)
+template <int N, int T, bool FAST> constexpr int zpass_c1_min_waves() { return T == N / 16 ? 3 : (FAST ? 6 : 5); }
 template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true, bool ZWT = false>
-__global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs a)
+__global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass_c1(const FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // one transform
@@ -1341,6 +1376,9 @@ __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs 
     float* raw = reinterpret_cast<float*>(fbuf);                           // [0]: S-(0) of the column, until the first exchange
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
+#ifdef OCEAN_CLOCKPROBE
+    ClockProbe clock_probe_(a.frame_seq);
+#endif
     start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (one 2048^2 tile: ocean_launch.h) -- ahead of every load: nothing is live across the wait
     TwiddleRegs<N, 1, T, P> twr;
     twr.load(a.tw, tid);
@@ -1389,10 +1427,12 @@ __global__ void __launch_bounds__(T, (FAST ? 6 : 5)) k_zpass_c1(const FrameArgs 
     static_assert(!ZWT || (!ZNT && !Z16), "write-through is a policy of the plain fp32 intermediates");
     if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
     else zpass_single_transforms<N, T, P, false, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+#ifdef OCEAN_CLOCKPROBE
+    clock_probe_.end();
+#endif
 }
 // tile sizes whose z pass has the single-transform form (the launcher picks it where it is faster: ocean_launch.h)
 template <int N> constexpr bool zpass_has_c1() { return N >= 1024; }
-template <int N> constexpr int zpass_c1_threads() { return N / 8; }          // one radix-8 butterfly per thread and stage
 // Where the single-transform form is the faster one (profiles/r04_zpass_experiments.txt; stream_maps: ocean_ctx.h, bit 2 = streamed
 // intermediates): 4096^2 always (three workgroups per CU instead of one: z pass 111 -> 95 us); 2048^2 and batches of 1024^2 with plain
 // intermediate stores (2048^2 24.4 -> 23.2 us and no split last round, 8 x 1024^2 38.1 -> 33.9); a lone 1024^2 tile keeps the
@@ -2190,5 +2230,16 @@ OCEAN_GEO(1024, 256, OCEAN_R(8, 8, 4, 4), 4, 256, Plan<1024>)
 OCEAN_GEO(2048, 512, OCEAN_R(8, 8, 8, 4), 4, 512, Plan<2048>)
 OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), 2, 512, Plan<4096>)
 #undef OCEAN_GEO
+
+// Threads and radix plan of the single-transform z pass (k_zpass_c1): one first-stage butterfly per thread.  The shipped form runs the tile
+// size's radix-8 plan with N / 8 threads; developer builds can run the radix-16 plan of fft_engine.h with N / 16 threads from a tile size up
+// (-DOCEAN_C1_R16_MIN=2048: one exchange and two barriers less per transform, a quarter fewer twiddle products, half the waves;
+// profiles/r06_zpass_experiments.txt).
+#ifndef OCEAN_C1_R16_MIN
+#define OCEAN_C1_R16_MIN 8192
+#endif
+template <int N> constexpr bool zpass_c1_r16() { return N >= OCEAN_C1_R16_MIN && N >= 2048; }
+template <int N> constexpr int zpass_c1_threads() { return zpass_c1_r16<N>() ? N / 16 : N / 8; }
+template <int N> struct C1Plan { using type = std::conditional_t<zpass_c1_r16<N>(), Plan<N>, typename Geo<N>::PR>; };
 
 }  // namespace ocean

@@ -84,8 +84,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #define OCEAN_ALLOW_Z(znt, z16, fast) \
         if constexpr (HAS1) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, lds_rows)) != hipSuccess) return e; \
         if constexpr (HAS2 && (znt || HAS2_PLAIN)) if ((e = allow_lds(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, lds_rows2)) != hipSuccess) return e; \
-        if constexpr (HASC1) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e; \
-        if constexpr (HASC1 && zpass_has_wt<N>() && !znt && !z16) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, fast, true>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e;
+        if constexpr (HASC1) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, znt, z16, fast>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e; \
+        if constexpr (HASC1 && zpass_has_wt<N>() && !znt && !z16) if ((e = allow_lds(k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, false, false, fast, true>, zpass_c1_lds_bytes<N>())) != hipSuccess) return e;
 #define OCEAN_ALLOW_Z2(fast) OCEAN_ALLOW_Z(false, false, fast) OCEAN_ALLOW_Z(true, false, fast) OCEAN_ALLOW_Z(false, true, fast) OCEAN_ALLOW_Z(true, true, fast)
         OCEAN_ALLOW_Z2(true) OCEAN_ALLOW_Z2(false)
 #undef OCEAN_ALLOW_Z2
@@ -156,11 +156,15 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // 512^2 11.6-12.3 / 7.7 / 18.6: from 256^2 up the z pass's 8-byte write-through stores and the x-axis workgroups' reads past the L2 cost more
     // than the launch they save (profiles/r05_small_tile_experiments.txt), so those sizes keep the merged x pass.
     constexpr bool HAS_ONE = (N <= 128 || (DEV && N <= 512)) && G::T_ROWS == G::T_C;      // (developer builds: up to 512^2, for the A/B of that log)
-    [[maybe_unused]] bool one_launch = HAS_ONE && !alone && tiles == 1 && a.mode <= 2 && fast && (stream_maps & 15) == 3 && !split && c->merged_x;
+    // (like the merged x pass only where every workgroup of the grid has a slot at once -- one per compute unit, the regime the hand-off recipe is
+    //  measured for: forward progress then never depends on the order in which workgroups are dispatched)
+    [[maybe_unused]] bool one_launch = HAS_ONE && !alone && tiles == 1 && a.mode <= 2 && fast && (stream_maps & 15) == 3 && !split && c->merged_x &&
+                                       ((unsigned)(N / 2 + 1) + hb_b + 2u * nb) <= cus;
 #ifdef OCEAN_DEVELOPER
     {   const char* const ol = getenv("OCEAN_ONE_LAUNCH");        // 0 / 1 (the form's own preconditions still hold)
         if (ol) one_launch = one_launch && atoi(ol) != 0; }
 #endif
+    c->handoff = merged_x || one_launch;      // (what recover_fault re-runs without a hand-off, should one of this frame's in-launch waits give up)
     int launches = 0;
     auto next_marks = [&](int kernel) -> hipEvent_t* {      // the event pair of the frame's next launch; remembers which kernel it times
         c->launch_kernel[launches] = kernel;
@@ -192,6 +196,12 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
                        (za.start_ramp ? OCEAN_LAUNCH_STAGGERED_START : 0u) | (split ? OCEAN_LAUNCH_SPLIT_ORDER : 0u);
         }
         hipEvent_t* mz = next_marks(0);
+#ifdef OCEAN_CLOCKPROBE
+        {   // diagnostic: this translation unit's copy of the probe pointer, set when the context's buffer changes (not per frame)
+            static unsigned long long* armed = nullptr;
+            if (armed != c->stamps) { armed = c->stamps; (void)hipMemcpyToSymbol(HIP_SYMBOL(ocean::g_clockprobe), &armed, sizeof(armed)); }
+        }
+#endif
         bool launched = false;
         // a SERIAL frame's fp32 intermediates go out write-through where that form exists (ocean_kernels.h: store_z, zpass_has_wt)
         if constexpr (HASC1 && zpass_has_wt<N>()) {
@@ -200,14 +210,14 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             if (const char* ev = getenv("OCEAN_Z_WT")) wt = wt && atoi(ev) != 0;     // (read per frame: A/B inside one process)
 #endif
             if (wt) {
-                if (fast) launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, true, true>, grid, block, lds, st, mz, za);
-                else launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, false, false, false, true>, grid, block, lds, st, mz, za);
+                if (fast) launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, false, false, true, true>, grid, block, lds, st, mz, za);
+                else launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, false, false, false, true>, grid, block, lds, st, mz, za);
                 launched = true;
                 if (launches == 1) c->last_launch[0].flags |= OCEAN_LAUNCH_WT_INTER;
             }
         }
 #define OCEAN_ZPASS3(znt, z16, fast) \
-        do { if (launched) break; if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename G::PR, znt, z16, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
+        do { if (launched) break; if constexpr (HASC1) { if (c1) { launch(k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, znt, z16, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
              if constexpr (HAS2 && (znt || HAS2_PLAIN)) { if (zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 2, fast>, grid, block, lds, st, mz, za); launched = true; break; } } \
              if constexpr (HAS1) { if (!c1 && !zw2) { launch(k_zpass<N, G::T_ROWS, typename G::PR, znt, z16, 1, fast>, grid, block, lds, st, mz, za); launched = true; } } } while (0)
 #define OCEAN_ZPASS2(znt, z16) \
@@ -328,6 +338,8 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
             launch_xb(7, rec_last);
         } else {
             launch_xb(3, 0);
+            // the normal map is final behind this launch: ocean_compute_waves_read starts its device-to-host copy here, beside the displacement pass
+            if (c->after_b) { if ((e = hipEventRecord(c->after_b, st)) != hipSuccess) return e; c->after_b_recorded = true; }
 #ifdef OCEAN_STAMPS
             arm(2);
 #endif
