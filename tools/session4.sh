@@ -1,0 +1,14 @@
+# round 6, GPU session 4: the z pass with the phase table + twiddle tables (full GPU suite, cycles per launch old / new, kernel times), the drop-in call
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r06_s4_pytest.txt 2>&1; echo "pytest exit $?" >> gpurun_out/r06_s4_pytest.txt
+for rep in 1 2; do for L in probe probe_r05z; do
+  echo "##### $L"; OCEAN_HIP_LIB=watersurfacerendering_amd/libocean_hip_$L.so timeout 300 python tools/slow_window.py 0 2>&1 | grep -E "^==|duration us|clock GHz|kilocycles"
+done; done > gpurun_out/r06_s4_cycles.txt 2>&1
+for rep in 1 2 3; do for L in default r05z; do
+  if [ "$L" = "default" ]; then unset OCEAN_HIP_LIB; else export OCEAN_HIP_LIB=watersurfacerendering_amd/libocean_hip_$L.so; fi
+  for cfg in "2048 1 1000" "4096 1 100" "1024 8 300"; do echo "[$L] $(python tools/kernel_times.py $cfg 2>&1 | grep -v amdgpu.ids)"; done
+  echo "[$L] $(python tools/depth_batch.py 2048 1 3 2>&1 | grep -v amdgpu.ids)"
+done; done > gpurun_out/r06_s4_times.txt 2>&1
+unset OCEAN_HIP_LIB
+bash tools/dropin_call.sh 400 > gpurun_out/r06_s4_dropin.txt 2>&1
+tail -4 gpurun_out/r06_s4_pytest.txt; cat gpurun_out/r06_s4_cycles.txt gpurun_out/r06_s4_times.txt gpurun_out/r06_s4_dropin.txt

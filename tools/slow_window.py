@@ -130,6 +130,8 @@ def window(label, nframes=4000):
 window("fresh0 (first serial frames of the process)")
 window("fresh1")
 window("fresh2")
+if SOAK_S <= 0:          # quick mode (A/B of kernel variants by cycles per launch): three windows, no soak
+    b.close(); child.terminate(); sys.exit(0)
 # ---- sustained load -------------------------------------------------------------------------------------------------------
 heavy = W.OceanBatch(2048, 1, 0); heavy.prepare(1); heavy.set_pipeline_depth(3)
 heavy2 = W.OceanBatch(1024, 8, 0); heavy2.prepare(2); heavy2.set_pipeline_depth(2)

@@ -134,7 +134,7 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMalloc(&c->omega, t * n2 * sizeof(float)));
     HIP_TRY(hipMalloc(&c->omega_q, t * n2 * sizeof(uint16_t)));
     HIP_TRY(hipMalloc(&c->base_freq, t * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->omega_q_overflow, sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&c->omega_q_overflow, 2 * sizeof(unsigned)));      // [0] some multiple needs more than 16 bits, [1] the largest multiple
     HIP_TRY(hipMalloc(&c->k1d, t * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->tw, n * sizeof(float2)));
     {
@@ -413,7 +413,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         dim3 g((unsigned)((n + 255) / 256), (unsigned)t);
         hipLaunchKernelGGL(k_init_k1d, g, dim3(256), 0, stream_of(c, 0), c->k1d, c->tparams, (int)n);
         dim3 g2((unsigned)((n2 + 255) / 256), (unsigned)t);
-        HIP_TRY(hipMemsetAsync(c->omega_q_overflow, 0, sizeof(unsigned), stream_of(c, 0)));
+        HIP_TRY(hipMemsetAsync(c->omega_q_overflow, 0, 2 * sizeof(unsigned), stream_of(c, 0)));
         hipLaunchKernelGGL(k_init_spectrum, g2, dim3(256), 0, stream_of(c, 0), c->h0, c->omega, c->omega_q, c->base_freq, c->omega_q_overflow,
                            xi_or_null ? (float2*)nullptr : c->xi, xi_or_null ? c->xi : (const float2*)nullptr,
                            c->k1d, c->tparams, (int)n);
@@ -482,9 +482,10 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     }
     SYNC_ALL(c);
     {
-        unsigned overflow = 1;
-        HIP_TRY(hipMemcpy(&overflow, c->omega_q_overflow, sizeof(unsigned), hipMemcpyDeviceToHost));
-        c->omega16 = overflow == 0;
+        unsigned ow[2] = {1u, 0xFFFFu};
+        HIP_TRY(hipMemcpy(ow, c->omega_q_overflow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
+        c->omega16 = ow[0] == 0;
+        c->wq_max = ow[1];
 #ifdef OCEAN_DEVELOPER      // A/B builds only (make variant ... DEFS=-DOCEAN_DEVELOPER): the shipped library reads no environment
         static const char* const w16_env = getenv("OCEAN_OMEGA16");
         if (w16_env && atoi(w16_env) == 0) c->omega16 = false;
@@ -542,7 +543,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     }
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
-    a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
+    a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq; a.wq_max = c->wq_max;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set]; a.hdone = c->hdone[set];
@@ -587,7 +588,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     // several frames in flight, or maps that would push everything else out of the 256 MiB memory-side cache anyway
     // (32 B/texel: 4096^2, 8 x 1024^2 ...): stream the maps past it.  A serial 2048^2 frame (134 MB of maps) is
     // faster with plain stores (76 vs 80 us), a serial 8 x 1024^2 batch (268 MB) with streamed ones (124 vs 150 us).
-    int stream_maps = (pipe || texels * 32.0 > 200.0e6) ? 3 : 0;
+    int stream_maps = (pipe || texels * 32.0 > c->tune.maps_stream_frac * c->tune.cache_bytes) ? 3 : 0;
     if (c->inter_bits == 16) stream_maps |= 8;          // bit 3: half2 intermediates (kernel variant, not a store policy)
     if (pipe) {
         // what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the memory-side
@@ -602,7 +603,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
         const bool jac = c->mode == OCEAN_MODE_JACOBIAN;
         const double inter = c->inter_bits == 16 ? (jac ? 14.0 : 8.0) : (jac ? 22.0 : 16.0);
         const double resident = texels * (10.0 + inter * c->depth);
-        if (resident > 300.0e6) stream_maps |= 4;
+        if (resident > c->tune.inter_stream_frac * c->tune.cache_bytes) stream_maps |= 4;
     }
     if (!pipe) stream_maps |= 16;                                               // this frame has the device to itself (which staggered start: ocean_launch.h)
 #ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
@@ -818,10 +819,24 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->nrm_final, 0));
         nst = c->copy_stream;
     }
-    HIP_TRY(hipMemcpyAsync(nrm, q, bytes, hipMemcpyDeviceToHost, nst));
+    // small maps into page-locked memory: a copy kernel (OceanTuning::copy_kernel_max_bytes); otherwise the runtime's copy
+    bool by_kernel = bytes <= c->tune.copy_kernel_max_bytes;
+    void* dev_dst[2] = {nullptr, nullptr};        // (looked up per call: the caller may have unregistered the range since the last one)
+    if (by_kernel) {
+        void* host[2] = {nrm, disp};
+        for (int k = 0; k < 2; ++k)
+            if (hipHostGetDevicePointer(&dev_dst[k], host[k], 0) != hipSuccess) { dev_dst[k] = nullptr; (void)hipGetLastError(); }
+        by_kernel = dev_dst[0] && dev_dst[1];
+    }
+    const size_t texels = bytes / sizeof(float4);
+    const unsigned blocks = (unsigned)((texels + 255) / 256 < 1024 ? (texels + 255) / 256 : 1024);
+    if (by_kernel) hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, nst, q, static_cast<float4*>(dev_dst[0]), texels);
+    else HIP_TRY(hipMemcpyAsync(nrm, q, bytes, hipMemcpyDeviceToHost, nst));
     HIP_TRY(hipEventRecord(c->copy_done[0], nst));
-    HIP_TRY(hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st));
+    if (by_kernel) hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, st, d, static_cast<float4*>(dev_dst[1]), texels);
+    else HIP_TRY(hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->copy_done[1], st));
+    HIP_TRY(hipGetLastError());
     rc = wait_frame(c, set);        // the frame's completion records (a poll): A, min, max -- the copies are still in flight
     if (rc == OCEAN_OK && c->fault_recoveries_seen != c->fault_recoveries) {
         // the frame was run again (an in-launch wait had given up): what the copies took may be the wrong frame's -- copy again, plainly
@@ -1456,13 +1471,9 @@ int ocean_algorithmic_bytes_per_launch(const ocean_t* c, int idx)
     //   x pass, b    pairs 1, 2 and the height plane 10 in (5; pair 3: 12 / 6), raw height 2 + normal map 16 out (+ 4: the Jacobian's two planes)
     //   x pass, disp pair 0 and the raw height 4 + 2 in (2 + 2; + 4 of the two planes), displacement map 16 out
     if (idx < 0 || idx > 2) return 0;
-    const bool half = c && c->inter_bits == 16, jac = c && c->mode == OCEAN_MODE_JACOBIAN;
-    const int h0 = (c && c->h0_bits == 16) ? 4 : 8, w = (c && c->prepared && !c->omega16) ? 2 : 1;
-    const int z_out = jac ? (half ? 8 : 16) : (half ? 7 : 14);
-    const int pair0 = half ? 2 : 4;
-    if (idx == 0) return h0 + w + z_out;
-    if (idx == 1) return (z_out - pair0) + 2 + 16 + (jac ? 4 : 0);
-    return pair0 + 2 + 16 + (jac ? 4 : 0);
+    int b[3];
+    ocean_launch_bytes_per_texel(c && c->inter_bits == 16, c && c->mode == OCEAN_MODE_JACOBIAN, c && c->h0_bits == 16, !(c && c->prepared && !c->omega16), b);
+    return b[idx];
 }
 
 int ocean_algorithmic_bytes_per_texel(const ocean_t* c)

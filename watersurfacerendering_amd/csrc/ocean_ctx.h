@@ -15,7 +15,61 @@
 constexpr int MAXD = 8;     // maximum pipeline depth (independent frame chains)
 constexpr int OCEAN_MAX_LAUNCHES = 5;   // launches per frame: three (five in the developer-only split order: ocean_launch.h)
 
+// ---- launch and store-policy heuristics: every measured constant in ONE place -----------------------------------------
+// The rules are written in quantities of the device and of the launch -- compute units x resident workgroups per unit (asked of the runtime:
+// hipOccupancyMaxActiveBlocksPerMultiprocessor), the memory-side cache, the bytes a launch moves -- not in tile sizes; rounds 2-5 had them as
+// `N == 2048 && tiles == 1`, 500 / 450 / 900 ticks and literal 200 / 300 MB.  Each constant cites the measurement that fitted it.
+struct OceanTuning {
+    // Memory-side (Infinity) cache of the device.  HIP has no query for it; MI355X_MICROARCH.md: 256 MiB.
+    double cache_bytes = 268435456.0;
+    // The maps are written once and never re-read by the pipeline: streamed past the cache (non-temporal stores) whenever frames are pipelined,
+    // and for a serial frame once the two maps of the frame alone exceed this fraction of the cache -- 200 MB: a serial 2048^2 frame (134 MB)
+    // is faster with plain stores (76 vs 80 us), a serial 8 x 1024^2 batch (268 MB) with streamed ones (124 vs 150 us); ocean_api.hip.
+    double maps_stream_frac = 0.745;
+    // Pipelined frames: what every frame re-reads -- spectrum + the intermediates of every chain in flight -- against the cache; beyond this
+    // fraction (300 MB) the intermediates are streamed too (2048^2 depth 3, 243 MB: 57-58 plain vs 59-60 streamed; depth 4, 310 MB: 61 vs
+    // 58.5; profiles/r02_layout_experiments.txt).
+    double inter_stream_frac = 1.118;
+    // Staggered start (ocean_kernels.h: start_ramp_wait).  A launch whose whole grid is resident at once on an otherwise idle device is a load
+    // burst followed by a store burst; spreading the workgroups' starts lets the early ones store while the late ones load.  The spread is a
+    // fraction of the launch's expected duration -- its algorithmic bytes at a nominal rate: 0.27 x bytes / 5.5 TB/s = 4.7 / 4.9 / 4.5 us for
+    // the three launches of a 2048^2 frame (k_xpass_b: its normal-map workgroups and their 24 B/texel), inside the flat optimum of 4-5 us
+    // measured for each (profiles/r04_zpass_experiments.txt item 10; round 5 re-measured the z pass's with write-through stores: flat from
+    // 2 to 5 us; rounds 4-5 shipped 5.0 / 4.5 / 4.5) ...
+    double ramp_frac = 0.27;
+    double ramp_rate_bytes_per_s = 5.5e12;
+    // ... twice that for the x passes of PIPELINED frames, which run beside the same launches of the other chains (item 11: 9 us; now 9.9 / 9.1) ...
+    double ramp_pipelined_x = 2.0;
+    // ... and only for launches that move at least this much: below it the bursts are too short to be worth a wait (1024^2, 23-29 MB per
+    // launch: z pass 14.5-15.3 -> 14.8-15.3, displacement pass 7.4-8.5 -> 8.2-9.8 us: a loss; 2048^2, 92-117 MB: -1 us per launch).
+    double ramp_min_bytes = 64.0e6;
+    // ... and whose resident round is at most this many workgroups per compute unit: a unit that is handed ten small workgroups staggers them by
+    // itself, and a rule that trusted the occupancy query alone lost 12 % on serial 5 x 1024^2 frames (z pass 33 -> 39-43 us; 3 and 4 tiles:
+    // -1 ... +1 %; round 6, profiles/r06_tuning_rules.txt).  The launches that gain hold 1-5 per unit.
+    unsigned ramp_max_wg_per_cu = 6;
+    // ocean_compute_waves_read: maps up to this size go to the host by a copy kernel (stores through the destination's device address), larger
+    // ones through the runtime's DMA engines: 2 x 4 MiB 160 us against 176-184, 2 x 16 MiB 625 against 617, 2 x 64 MiB 2470 against 2384 us
+    // (tools/ubench/d2h.hip, round 6).
+    size_t copy_kernel_max_bytes = (size_t)8 << 20;
+    // Merged x pass / one-launch frame (in-launch hand-offs): only where every workgroup of the grid has a compute unit to itself
+    // (MI355X_MICROARCH.md, inter-workgroup visibility: the regime the recipe is measured for).
+    unsigned handoff_wg_per_cu = 1;
+};
+// bytes per texel the three launches of a frame move (fp32 FULL7: 23 / 28 / 22; ocean_algorithmic_bytes_per_launch has the derivation)
+inline void ocean_launch_bytes_per_texel(bool half_inter, bool jacobian, bool h0_half, bool omega16, int out[3])
+{
+    const int h0 = h0_half ? 4 : 8, w = omega16 ? 1 : 2;
+    const int z_out = jacobian ? (half_inter ? 8 : 16) : (half_inter ? 7 : 14);
+    const int pair0 = half_inter ? 2 : 4;
+    out[0] = h0 + w + z_out;
+    out[1] = (z_out - pair0) + 2 + 16 + (jacobian ? 4 : 0);
+    out[2] = pair0 + 2 + 16 + (jacobian ? 4 : 0);
+}
+
 struct ocean_ctx {
+    OceanTuning tune;               // the heuristics' constants (defaults above; nothing changes them at run time)
+    int occ_n = 0;                  // tile size occ_* were asked for: resident workgroups per compute unit of the single-transform z pass and of
+    int occ_z = 0, occ_b = 0, occ_d = 0;    //   the two x passes on this device (hipOccupancyMaxActiveBlocksPerMultiprocessor; ocean_launch.h)
     uint32_t n = 0;
     uint32_t tiles = 0;
     int device = 0;
@@ -49,6 +103,7 @@ struct ocean_ctx {
     float* base_freq = nullptr;     // [tiles]
     unsigned* omega_q_overflow = nullptr;
     bool omega16 = false;           // every multiple fits 16 bits (decided at ocean_prepare)
+    unsigned wq_max = 0xFFFFu;      // the largest of them over all tiles (FrameArgs::wq_max: the size of the z pass's phase table)
     float* k1d = nullptr;
     float2* tw = nullptr;
     float2* z[MAXD] = {};

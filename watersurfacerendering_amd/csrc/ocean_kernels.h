@@ -175,6 +175,8 @@ struct FrameArgs {
     const float* omega;      // [tiles][N][N]   quantised dispersion, same layout
     const uint16_t* omega_q; // [tiles][N][N]   the same as the integer multiple of base_freq (null: use omega); see k_zpass
     const float* base_freq;  // [tiles]
+    unsigned wq_max;         // largest 16-bit multiple in omega_q over all tiles of the context (k_init_spectrum): the phase table of the
+                             // single-transform z pass has wq_max + 1 entries (k_zpass_c1, FAST)
     const __half2* h0h;      // [tiles][N][N]   optional fp16 copy of h0 scaled by 1/h0_inv_scale[tile] (null = fp32)
     const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
@@ -336,6 +338,11 @@ __global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ ome
     // 4 per texel) and rebuild the same float, float(steps) * base_freq, unless some multiple needs more bits
     omega_q[tile * n2 + i] = (uint16_t)(steps < 65536.0f ? (unsigned)steps : 0u);
     if (!(steps < 65536.0f)) atomicOr(omega_q_overflow, 1u);
+    // [1]: the largest multiple (one atomic per wave): the size of the z pass's per-frame phase table
+    unsigned mq = steps < 65536.0f ? (unsigned)steps : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned other = (unsigned)__shfl_xor((int)mq, o); mq = other > mq ? other : mq; }
+    if ((threadIdx.x & 63) == 0) atomicMax(omega_q_overflow + 1, mq);
 }
 
 // fp16 spectrum variant (BASELINE config 4): h0 stored as half2 scaled per tile so
@@ -481,7 +488,8 @@ template <int N, bool ZNT> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC
 #else
 template <int N, bool ZNT> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC_NT_MIN && !ZNT; }
 #endif
-template <int N, bool H16, bool W16, bool ZNT = false>
+// RAWW (with W16, fp32 spectrum): w.x carries the two 16-bit multiples as loaded (bit pattern) -- the caller looks the phases up in a table
+template <int N, bool H16, bool W16, bool ZNT = false, bool RAWW = false>
 __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
                                                 float4& ha, float2& hb0, float2& hb1, float2& w)
 {
@@ -503,7 +511,8 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
         const nt2 v0 = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(h0 + m0)), v1 = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(h0 + m1));
         ha = make_float4(va.x, va.y, va.z, va.w); hb0 = make_float2(v0.x, v0.y); hb1 = make_float2(v1.x, v1.y);
         const unsigned two = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g));
-        w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+        if constexpr (RAWW) w = make_float2(__uint_as_float(two), 0.0f);
+        else w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
         return;
     }
     if constexpr (H16) {
@@ -520,7 +529,8 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
     }
     if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
         const unsigned two = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
-        w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+        if constexpr (RAWW) w = make_float2(__uint_as_float(two), 0.0f);
+        else w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
     } else {
         w = *reinterpret_cast<const float2*>(a.omega + tile * n2 + g);
     }
@@ -538,6 +548,24 @@ __device__ __forceinline__ void animate_with_mirror(float2 h0a, float2 h0b, floa
     av = height_re(h0a.x, h0a.y, c, s);
     bv = height_re(h0b.x, h0b.y, c, s);
 }
+
+// the same with the phase's (sin, cos) already known (the phase table of k_zpass_c1)
+__device__ __forceinline__ void animate_with_phase(float2 h0a, float2 h0b, float2 sc, float& av, float& bv)
+{
+    av = height_re(h0a.x, h0a.y, sc.y, sc.x);
+    bv = height_re(h0b.x, h0b.y, sc.y, sc.x);
+}
+// Phase table (round 6).  The dispersion is a 16-bit multiple q of the base frequency, so an element's phase is a function of q alone, and a
+// tile has few distinct q (301 at 2048^2 with the reference's defaults, 426 at 4096^2): every workgroup evaluates sincos ONCE per value --
+// entry q = sincos(fl(fl(q * base) * t)), the operations and the order of the per-element form (animate_with_mirror), hence the same bits --
+// into the FFT image's LDS, which is idle until the first exchange, while its spectrum loads are in flight; phase 1 then looks the elements
+// up.  One or two sincos per thread instead of eight: 160 vector instructions less per wave of 1 417 (profiles/r06_zpass_experiments.txt).
+// The table has FrameArgs::wq_max + 1 entries; the launcher falls back to the all-forms instantiation (per-element sincos) when that exceeds
+// the image (ocean_launch.h).
+#ifndef OCEAN_C1_PHASE_TABLE      // developer A/B: 0 = per-element sincos in every instantiation, as in rounds 2-5
+#define OCEAN_C1_PHASE_TABLE 1
+#endif
+template <int N> constexpr unsigned zpass_phase_table_capacity() { return (unsigned)fft_lds_elems<N, 1>() - 1u; }     // (the last slot carries S-(0))
 
 // ---- half-spectrum storage geometry -------------------------------------------
 #ifndef OCEAN_ZTILE
@@ -1267,9 +1295,10 @@ struct ClockProbe {
 // workgroups per CU, the same number of waves, and each one's load burst and store tail travel under the other's transforms.  Same radix
 // plan, same inputs (zpass_input), same twiddles: bit-identical to the other forms (tests/test_variants_gpu.py).
 // ============================================================================
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false>
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false, class TT = NoTwiddleTables>
 __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float (&kzr)[P::r[0]],
-                                                        TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb)
+                                                        TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb,
+                                                        const TT& tt = TT{})
 {
     using HF = Half<N>;
     // kz of the first stage's inputs: thread j reads elements j + i * (N / R0), i = 0 .. R0-1, in every one of the four batches -- the
@@ -1311,7 +1340,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, zo.pos(nb, p, u, i), v, su); };
-            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
             auto in = [&](int e, int, int, int i) -> c32 {
@@ -1319,7 +1348,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
         }
     }
     if ((a.mode == 0 || a.mode == 3) && (a.zmask & 4)) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
@@ -1328,7 +1357,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
         };
         auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
     }
     if constexpr (zpass_half_height<N>()) {
         if ((a.zmask & 8) && !jac) {      // the height as a real-input transform: half the size + one split step (zpass_height_half)
@@ -1357,14 +1386,23 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             if (jac) store_z<ZNT, Z16, ZWT>(z3, zo.pos(nb, p, u, i), v, s3);
             else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
         };
-        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
     }
 }
 
-template <int N> constexpr size_t zpass_c1_lds_bytes() { return sizeof(c32) * fft_lds_elems<N, 1>() + sizeof(float) * N; }
-
 // (the instantiations that carry all four forms of the spectrum -- !FAST: fp16 copy, fp32 dispersion -- need a few registers more than the
 //  80 of six waves per SIMD and spilled 24-28 bytes per lane under that cap: they ask for five, 96 registers, no scratch)
+// Twiddle-power tables of the single-transform z pass (fft_engine.h: TwiddleTables), behind the S+ table in LDS: the radix-8 stages with NS = 8
+// and NS = 64 at 2048 (504 entries, 4 KB: 30 KB per workgroup, five per CU -- the 1025 workgroups of a tile need 4.004), the NS = 8 stage alone
+// at 1024 (its other stages are radix 4) and at 4096 (a 4 KB table would cost the third workgroup per CU); none with a radix-16 plan.
+#ifndef OCEAN_C1_TWTAB
+#define OCEAN_C1_TWTAB 1
+#endif
+template <int N, class P> using C1TwiddleTables = TwiddleTables<N, P, (OCEAN_C1_TWTAB ? (N == 2048 ? 64 : 8) : 0)>;
+template <int N, class P> constexpr size_t zpass_c1_lds_bytes_for()
+{
+    return sizeof(c32) * fft_lds_elems<N, 1>() + sizeof(float) * N + sizeof(c32) * C1TwiddleTables<N, P>::total();
+}
 // (a radix-16 plan -- N / 16 threads, two waves per 2048-point workgroup -- may use the registers of three waves per SIMD: six workgroups per CU)
 template <int N, int T, bool FAST> constexpr int zpass_c1_min_waves() { return T == N / 16 ? 3 : (FAST ? 6 : 5); }
 template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true, bool ZWT = false>
@@ -1373,7 +1411,9 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // one transform
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 1>());    // S+ [N]
-    float* raw = reinterpret_cast<float*>(fbuf);                           // [0]: S-(0) of the column, until the first exchange
+    // until the first exchange the image holds, in the usual form (FAST), the phase table [0 .. wq_max] and in its last slot S-(0) of the column
+    constexpr bool PT = FAST && OCEAN_C1_PHASE_TABLE;
+    float* raw = reinterpret_cast<float*>(fbuf + (PT ? fft_lds_elems<N, 1>() - 1 : 0));
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
 #ifdef OCEAN_CLOCKPROBE
@@ -1382,6 +1422,11 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (one 2048^2 tile: ocean_launch.h) -- ahead of every load: nothing is live across the wait
     TwiddleRegs<N, 1, T, P> twr;
     twr.load(a.tw, tid);
+    // the early stages' twiddle powers, once per workgroup for all four transforms (fft_engine.h: TwiddleTables); published by phase 1's barrier
+    using TT = C1TwiddleTables<N, P>;
+    c32* twtab = reinterpret_cast<c32*>(sp + N);
+    TT::build(twtab, a.tw, tid);
+    const TT tt{twtab};
     const int nb = xcd_swizzle((int)blockIdx.x, N / 2 + 1);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
@@ -1401,13 +1446,30 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
             float2 hb0[PB], hb1[PB], wv[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u)
-                zpass_load_pair<N, H16, W16, ZNT>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+                zpass_load_pair<N, H16, W16, ZNT, PT>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+            if constexpr (PT) {
+                if (ub == 0) {          // the phase table, while the loads travel (see animate_with_phase)
+                    for (unsigned q = (unsigned)tid; q <= a.wq_max; q += (unsigned)T) {
+                        const float wt = mul_nocontract(mul_nocontract((float)q, base), t);
+                        float sn, cs;
+                        sincos_f32(wt, sn, cs);
+                        fbuf[q] = make_float2(sn, cs);
+                    }
+                    __syncthreads();
+                }
+            }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int n = 2 * (tid + (ub + u) * T);
                 float a0, b0, a1, b1;
-                animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
-                animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
+                if constexpr (PT) {
+                    const unsigned two = __float_as_uint(wv[u].x);
+                    animate_with_phase(make_float2(ha[u].x, ha[u].y), hb0[u], fbuf[two & 0xffffu], a0, b0);
+                    animate_with_phase(make_float2(ha[u].z, ha[u].w), hb1[u], fbuf[two >> 16], a1, b1);
+                } else {
+                    animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
+                    animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
+                }
                 *reinterpret_cast<float2*>(sp + n) = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
                 if (n == 0) raw[0] = 0.5f * (a0 - b0);          // S-(0), for everybody (the FFT image is not in use yet)
             }
@@ -1425,8 +1487,8 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     __syncthreads();
     const float sm0 = raw[0];
     static_assert(!ZWT || (!ZNT && !Z16), "write-through is a policy of the plain fp32 intermediates");
-    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
-    else zpass_single_transforms<N, T, P, false, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb, tt);
+    else zpass_single_transforms<N, T, P, false, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb, tt);
 #ifdef OCEAN_CLOCKPROBE
     clock_probe_.end();
 #endif
@@ -2056,6 +2118,14 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
 }
 
 #ifdef OCEAN_INIT_KERNELS
+// Device-to-host copy of a map by a kernel that stores into the page-locked destination through its device address (ocean_compute_waves_read,
+// small maps): 16 bytes per lane, grid-stride.  Two maps of 4 MiB land in 160 us this way against 176-184 us through the runtime's DMA engines
+// (which win from 16 MiB per map up: 56.3 against 54.3 GB/s at 64 MiB; tools/ubench/d2h.hip, profiles/r06_dropin_call.txt).
+__global__ void k_copy_out(const float4* __restrict__ src, float4* __restrict__ dst, size_t texels)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // Packed-map gather at half the bytes (the gather is xGMI-bound): one RGBA32F texel -> four halves
 // (round to nearest even; |values| of both maps are far below the largest half, 65504, for any sea the reference
 // parameters can describe -- larger values saturate to +-inf like any float -> half conversion).
@@ -2241,5 +2311,6 @@ OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), 2, 512, Plan<4096>)
 template <int N> constexpr bool zpass_c1_r16() { return N >= OCEAN_C1_R16_MIN && N >= 2048; }
 template <int N> constexpr int zpass_c1_threads() { return zpass_c1_r16<N>() ? N / 16 : N / 8; }
 template <int N> struct C1Plan { using type = std::conditional_t<zpass_c1_r16<N>(), Plan<N>, typename Geo<N>::PR>; };
+template <int N> constexpr size_t zpass_c1_lds_bytes() { return zpass_c1_lds_bytes_for<N, typename C1Plan<N>::type>(); }
 
 }  // namespace ocean

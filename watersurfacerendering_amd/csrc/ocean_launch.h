@@ -44,28 +44,19 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb_b = xpass_height_groups<N, C>(), nb = (HF::NU + C - 1) / C;
-    // Staggered start (ocean_kernels.h: start_ramp_wait) for the frames it was measured to pay for: ONE 2048^2 tile -- every launch one resident
-    // round --, every mode and precision.  A serial frame (bit 4 of stream_maps: it has the device to itself): z pass 5.0 us, normal-map workgroups
-    // and displacement pass 4.5 us; a pipelined frame, whose launches run beside the same launches of the other chains
-    // (profiles/r04_zpass_experiments.txt items 9-12): 5.0 / 9.0 / 9.0 us.
-    const bool fast = !a.h0h && a.omega_q;       // the usual form of the spectrum: fp32 h0, 16-bit dispersion
-    // ... and only where the launch IS one resident round on this device: every workgroup of the grid has a slot at once (compute units x
-    // workgroups per unit: six of the single-transform z pass -- 25.6 KB of LDS, launch bounds; five of its all-forms instantiations --, two of either x pass -- 70 KB of LDS);
-    // on a smaller or partitioned device the late workgroups would wait twice.  ocean_set_start_ramp(ctx, 0) switches it off altogether.
-    const bool ramp = N == 2048 && tiles == 1 && c->start_ramp;
+    // the usual form of the spectrum: fp32 h0, 16-bit dispersion -- and, where the tile size has the single-transform z pass, few enough distinct
+    // multiples for its phase table (ocean_kernels.h: zpass_phase_table_capacity; 301 entries at 2048^2 with the reference's defaults against
+    // 2303); otherwise the instantiations that carry every form of the spectrum run (per-element sincos)
+    const bool fast = !a.h0h && a.omega_q && (!zpass_has_c1<N>() || a.wq_max < zpass_phase_table_capacity<N>());
     const bool alone = (stream_maps & 16) != 0;
     const unsigned cus = (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
-    int ramp_z = (ramp && (N / 2 + 1) <= (fast ? 6u : 5u) * cus) ? 500 : 0;
-    int ramp_b = (ramp && (hb_b + nb) <= 2u * cus) ? (alone ? 450 : 900) : 0;
-    int ramp_d = (ramp && nb <= 2u * cus) ? (alone ? 450 : 900) : 0;
-#ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
-    {   static const char* const rz = getenv("OCEAN_RAMP_Z"); static const char* const rb = getenv("OCEAN_RAMP_B"); static const char* const rd = getenv("OCEAN_RAMP_D");
-        static const char* const ra = getenv("OCEAN_RAMP_ANY");     // 1: every size and batch
-        const bool on = ramp || (ra && atoi(ra) == 1);
-        if (rz && on) ramp_z = atoi(rz);
-        if (rb && on) ramp_b = atoi(rb);
-        if (rd && on) ramp_d = atoi(rd); }
-#endif
+    // Staggered start (ocean_kernels.h: start_ramp_wait; the rule and its constants: OceanTuning, ocean_ctx.h).  A launch gets one when its WHOLE
+    // grid is resident at once on this device -- grid <= compute units x resident workgroups per unit, the latter asked of the runtime for the
+    // kernels in question -- and it moves enough bytes for the bursts to be worth separating; the spread is a fraction of its expected duration.
+    // In practice: the three launches of one 2048^2 tile (every mode and precision), 4.2 / 5.1 / 4.0 us serial, the x passes twice that when
+    // pipelined; not 1024^2 (too few bytes), not 4096^2 or batches (several rounds, which overlap by themselves).  ocean_set_start_ramp(ctx, 0)
+    // switches it off altogether (a device shared with other work: a workgroup's wait is simply lost).
+    int ramp_z = 0, ramp_b = 0, ramp_d = 0;          // (computed below, once the kernels' attributes are set)
     // function attributes are per device; a context belongs to one device and one thread, so the flag
     // lives in the context (no process-wide state shared between contexts or threads)
     // Which forms of the z pass a tile size has (ocean_kernels.h).  ZW1: one column, two-transform batches (four-transform batches at 256 /
@@ -104,6 +95,43 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
 #undef OCEAN_ALLOW_X
         c->attr_n = (uint32_t)N;
     }
+    if (c->start_ramp && cus) {
+        if (c->occ_n != N) {
+            int oz = 0, ob = 0, od = 0;
+            if constexpr (zpass_has_c1<N>())
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oz, k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, false, false, true>,
+                                                                   zpass_c1_threads<N>(), zpass_c1_lds_bytes<N>());
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_xpass_b<N, C, G::T_C, typename G::PC, false, false, false>, G::T_C, lds_b);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&od, k_xpass_disp<N, C, G::T_C, typename G::PC, false, false, false>, G::T_C, lds_m);
+            (void)hipGetLastError();
+            c->occ_z = oz; c->occ_b = ob; c->occ_d = od; c->occ_n = N;
+        }
+        int bpt[3];
+        ocean_launch_bytes_per_texel((stream_maps & 8) != 0, a.mode == 3, a.h0h != nullptr, a.omega_q != nullptr, bpt);
+        const OceanTuning& tu = c->tune;
+        const double texels = (double)tiles * N * N;
+        auto ramp_ticks = [&](int bytes_per_texel, unsigned workgroups, int per_cu, double scale) -> int {
+            const double bytes = texels * bytes_per_texel;
+            const unsigned slots = (unsigned)per_cu < tu.ramp_max_wg_per_cu ? (unsigned)per_cu : tu.ramp_max_wg_per_cu;
+            if (per_cu <= 0 || workgroups > slots * cus || bytes < tu.ramp_min_bytes) return 0;
+            return (int)(tu.ramp_frac * scale * bytes / tu.ramp_rate_bytes_per_s * 1.0e8 + 0.5);      // 10 ns ticks (s_memrealtime)
+        };
+        // (the instantiations that carry every form of the spectrum hold one workgroup per unit less: launch bounds 5 instead of 6 waves per SIMD)
+        ramp_z = ramp_ticks(bpt[0], (unsigned)(N / 2 + 1) * tiles, c->occ_z - (fast ? 0 : 1), 1.0);
+        // k_xpass_b: over its NORMAL workgroups and their bytes alone -- the height workgroups (2 B/texel in, 2 out) write next to nothing and all
+        // start at once (item 10); the Jacobian mode's few workgroups beyond one round do not change the picture (item 12: same gain)
+        ramp_b = ramp_ticks(bpt[1] - 4, (hb_b + nb) * tiles, c->occ_b, alone ? 1.0 : tu.ramp_pipelined_x);
+        ramp_d = ramp_ticks(bpt[2], nb * tiles, c->occ_d, alone ? 1.0 : tu.ramp_pipelined_x);
+    }
+    [[maybe_unused]] const bool ramp = ramp_z || ramp_b || ramp_d;
+#ifdef OCEAN_DEVELOPER      // A/B builds only: the shipped library reads no environment
+    {   static const char* const rz = getenv("OCEAN_RAMP_Z"); static const char* const rb = getenv("OCEAN_RAMP_B"); static const char* const rd = getenv("OCEAN_RAMP_D");
+        static const char* const ra = getenv("OCEAN_RAMP_ANY");     // 1: every size and batch
+        const bool on = ramp || (ra && atoi(ra) == 1);
+        if (rz && on) ramp_z = atoi(rz);
+        if (rb && on) ramp_b = atoi(rb);
+        if (rd && on) ramp_d = atoi(rd); }
+#endif
 #ifdef OCEAN_STAMPS
     // diagnostic: stamps are recorded for ONE kernel of the frame (env OCEAN_DEBUG_STAMP_KERNEL = 0, 1, 2)
     static unsigned long long* null_ptr = nullptr;
@@ -145,7 +173,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // hand-off's three dependent memory round trips cost more than the kernel boundary they replace: 512^2 16.6 -> 18.2 us); PIPELINED frames
     // of one tile up to 512^2, which are bound by the rate of launches, not by any kernel (512^2, depth 4: 13.2-14.9 -> 8.0 us per frame).
     bool merged_x = xmerge_pays<N>(alone) && tiles == 1 && a.mode != 3 && !split && c->merged_x &&
-                    (hb_b + 2u * nb) <= (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
+                    (hb_b + 2u * nb) <= c->tune.handoff_wg_per_cu * cus;
 #ifdef OCEAN_DEVELOPER
     {   const char* const xm = getenv("OCEAN_XMERGE");            // 0 / 1: force (any size, any batch; still not the Jacobian mode)
         if (xm) merged_x = atoi(xm) != 0 && a.mode != 3 && !split; }
@@ -159,7 +187,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     // (like the merged x pass only where every workgroup of the grid has a slot at once -- one per compute unit, the regime the hand-off recipe is
     //  measured for: forward progress then never depends on the order in which workgroups are dispatched)
     [[maybe_unused]] bool one_launch = HAS_ONE && !alone && tiles == 1 && a.mode <= 2 && fast && (stream_maps & 15) == 3 && !split && c->merged_x &&
-                                       ((unsigned)(N / 2 + 1) + hb_b + 2u * nb) <= cus;
+                                       ((unsigned)(N / 2 + 1) + hb_b + 2u * nb) <= c->tune.handoff_wg_per_cu * cus;
 #ifdef OCEAN_DEVELOPER
     {   const char* const ol = getenv("OCEAN_ONE_LAUNCH");        // 0 / 1 (the form's own preconditions still hold)
         if (ol) one_launch = one_launch && atoi(ol) != 0; }
