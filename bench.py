@@ -359,6 +359,36 @@ def measure_config(W, n, tiles, device, steps, warmup, h0_bits=32, depth=1, mode
     return out
 
 
+def measure_dropin_call(W):
+    """The real drop-in call: the reference's `WSTessendorf::ComputeWaves` through the C++ adaptor of
+    include/WSTessendorf.hpp -- synthesis + BOTH maps in the caller's host vectors, blocking (WaterSurfaceMesh.cpp:145-154 + 701-755) -- at
+    512^2 (the reference's default size), 1024^2 (its GUI's largest) and 2048^2, with the PCIe rate the call achieves over the maps' bytes.
+    tests/cpp/adaptor_demo.cpp is compiled here (g++, a few seconds) and run as a child process; sidecar only, never the headline."""
+    import re
+    import shutil
+    import tempfile
+    lib_dir = os.path.dirname(W._abi.LIB_PATH)
+    tmp = tempfile.mkdtemp(prefix="ocean_dropin_")
+    try:
+        exe = os.path.join(tmp, "adaptor_demo")
+        cc = subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adaptor_demo.cpp"),
+                             "-o", exe, "-L", lib_dir, "-locean_hip", "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"],
+                            capture_output=True, text=True, timeout=300)
+        if cc.returncode != 0:
+            return {"error": "g++: " + cc.stderr[-300:]}
+        out = {"what": "WSTessendorf::ComputeWaves(t) of include/WSTessendorf.hpp from a C++ host = ocean_compute_waves_read: the frame + both maps "
+                       "into page-locked host vectors, blocking; us per call (mean of `frames` back-to-back calls), GB/s = 32 B/texel over that time"}
+        for n, frames in ((512, 400), (1024, 200), (2048, 100)):
+            r = subprocess.run([exe, str(n), "1.5", str(frames)], capture_output=True, text=True, timeout=300)
+            m = re.search(r"read-out of both maps: ([0-9.]+) us/frame = ([0-9.]+) GB/s", r.stderr)
+            out[f"{n}x{n}"] = {"us_per_call": float(m.group(1)), "pcie_GBps": float(m.group(2)), "frames": frames} if m else {"error": (r.stderr or r.stdout)[-200:]}
+        return out
+    except Exception as exc:  # noqa: BLE001  (an extra: its failure is reported, nothing else depends on it)
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def measure_sync_calls(W, n, device, calls=2000):
     """Latency distribution of the synchronous ComputeWaves (the reference's call shape, WaterSurfaceMesh.cpp:145-154: one blocking call per
     frame, returns the amplitude), twice: the calling thread as the scheduler places it, and pinned to one CPU with the collector off.  The
@@ -964,6 +994,7 @@ def main():
             extra["512x512_single_tile_depth4"] = measure_config(W, 512, 1, local_rank, 2000, 500, depth=4)
             extra["512x512_choppy5_single_tile_depth1"] = measure_config(W, 512, 1, local_rank, 2000, 500, mode=1)
             extra["256x256_height1_single_tile_depth1"] = measure_config(W, 256, 1, local_rank, 2000, 500, mode=2)
+            extra["dropin_call"] = measure_dropin_call(W)
             extra["512x512_synchronous_calls"] = measure_sync_calls(W, 512, local_rank)
             extra["2048x2048_synchronous_calls"] = measure_sync_calls(W, 2048, local_rank)
             extra["vertex_stage_512"] = measure_consumer(W, 512, local_rank)

@@ -172,9 +172,10 @@ int ocean_read_maps(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float
  * memcpy's of the finished maps (WaterSurfaceMesh.cpp:145-154, 701-755): out_amp[tiles] (may be NULL), disp / nrm = tiles*N*N*4 floats each
  * (neither NULL).  Same results as ocean_compute_waves + ocean_read_maps(0, tiles), sooner: the normal map is final when the frame's second
  * launch ends, so its device-to-host copy runs on a copy stream beside the displacement pass, and the displacement map's copy follows behind
- * its kernel on the frame's stream -- two DMA engines, one PCIe link kept busy from the second launch on; the call returns from a poll of
- * the two copies' events, not from a stream synchronisation.  Register the destinations with ocean_host_register for true DMAs (pageable
- * memory still works: staged, blocking copies).                                                                                            */
+ * its kernel on the frame's stream -- one PCIe link kept busy from the second launch on; the call returns from a poll of the two copies'
+ * events, not from a stream synchronisation.  Maps up to 8 MiB each go out by a copy kernel that stores through the destination's device
+ * address (2 x 4 MiB: 160 us against 176-184 us through the DMA engines), larger ones through the runtime's DMA engines (56 GB/s at 64 MiB).
+ * Register the destinations with ocean_host_register for that (pageable memory still works: staged, blocking copies).                      */
 int ocean_compute_waves_read(ocean_t* ctx, float t, float* out_amp, float* disp, float* nrm);
 
 /* Asynchronous read-out (the upload path after ComputeWaves,
@@ -184,6 +185,8 @@ int ocean_compute_waves_read(ocean_t* ctx, float t, float* out_amp, float* disp,
  * it, ordered after that frame on its stream, without blocking the caller; the copy is
  * complete after ocean_synchronize.  With an unregistered (pageable) destination the call
  * still works but degrades to a synchronous copy.                                       */
+/* (Registrations are process-wide, like the runtime's own; the library keeps a guarded list of the ranges registered through it so that
+ * ocean_compute_waves_read finds their device addresses without asking the runtime on every call -- the one piece of state outside a context.) */
 int ocean_host_register(void* host_ptr, size_t bytes);
 int ocean_host_unregister(void* host_ptr);
 int ocean_read_maps_async(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);

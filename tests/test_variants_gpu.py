@@ -34,6 +34,22 @@ T_FRAME = 1.7
 LONG_PERIOD = 4.0e5          # dispersion multiples beyond 16 bits at every size used here -> the fp32 array
 
 
+
+def _compute_units():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
+
+def handoff_grid_fits(n, one_launch=False):
+    """The launcher gives a frame an in-launch hand-off (merged x pass, one-launch frame) only where every workgroup of that grid has a compute
+    unit to itself on THIS device (ocean_launch.h, OceanTuning::handoff_wg_per_cu): the expectation follows the device's CU count, not the tile
+    size alone.  x passes: C = 4 rows per workgroup below 4096."""
+    c = 4 if n < 4096 else 2
+    nu = n // 2 + 1
+    hb, nb = (nu + 2 * c - 1) // (2 * c), (nu + c - 1) // c
+    return (nu if one_launch else 0) + hb + 2 * nb <= _compute_units()
+
+
 def chan_err(a, b):
     out = []
     for c in range(4):
@@ -172,11 +188,11 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
             stag = A.OCEAN_LAUNCH_STAGGERED_START                  # not a variant: the same instantiation, started differently
             # nor is the merged x pass (round 5): k_xpass_b's instantiation with its DISP workgroups in the same launch -- single small tiles, not the Jacobian mode
             merged = A.OCEAN_LAUNCH_MERGED_X
-            assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= (128 if depth == 1 else 512) and tiles == 1 and not jac), what
+            assert bool(xb["flags"] & merged) == bool(xd["flags"] & merged) == (n <= (128 if depth == 1 else 512) and tiles == 1 and not jac and handoff_grid_fits(n)), what
             # ... and the whole frame as ONE launch (k_frame: the bodies of k_zpass and k_xpass_b in one grid): pipelined frames of one tile up to
             # 128^2 in the usual form (fp32 spectrum, 16-bit dispersion, fp32 intermediates)
             one = A.OCEAN_LAUNCH_ONE_LAUNCH
-            want_one = n <= 128 and tiles == 1 and depth > 1 and not (jac or z16 or h16 or w32)
+            want_one = n <= 128 and tiles == 1 and depth > 1 and not (jac or z16 or h16 or w32) and handoff_grid_fits(n, one_launch=True)
             assert all(bool(li["flags"] & one) == want_one for li in (z, xb, xd)), what
             if want_one:        # (its launch record carries no store-policy flags of the z pass: mapped onto the three-launch variant it replaces)
                 assert z["grid_x"] == xb["grid_x"] == xd["grid_x"] and xb["flags"] & A.OCEAN_LAUNCH_NT_MAPS, what
@@ -309,7 +325,7 @@ def test_merged_x_pass_delivers_the_bits_of_the_three_launch_frame(n, oracles):
         d2, q2, h2, a2, l2 = frames(True, mode, bits, depth, sync)
         assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l1), what
         # pipelined frames in the usual form go one step further: the whole frame as ONE launch (k_frame)
-        assert all(bool(li["flags"] & A.OCEAN_LAUNCH_ONE_LAUNCH) == (n <= 128 and depth > 1 and bits == 32) for li in l2), what
+        assert all(bool(li["flags"] & A.OCEAN_LAUNCH_ONE_LAUNCH) == (n <= 128 and depth > 1 and bits == 32 and handoff_grid_fits(n, one_launch=True)) for li in l2), what
         if n > 128 and depth == 1:          # serial frames from 256^2 up keep three launches (the hand-off costs more than the boundary it replaces)
             assert not any(li["flags"] & A.OCEAN_LAUNCH_MERGED_X for li in l2), what
         else:

@@ -117,6 +117,18 @@ def window(label, nframes=4000):
     print(f"   duration x clock (kilocycles per launch)  median {p(dur * clk, 50):.2f}  p05 {p(dur * clk, 5):.2f}  p95 {p(dur * clk, 95):.2f}   "
           f"slow ones {np.mean((dur * clk)[slow]) if slow.any() else float('nan'):.2f}  others {np.mean((dur * clk)[~slow]):.2f}")
     print("   per-XCC median clock GHz: " + " ".join(f"{v:.3f}" for v in per_xcc))
+    # where the workgroups ran: per launch, workgroups per XCC and per compute unit (XCC id + SE / SH / CU bits 8..15 of HW_ID), and how long
+    # each XCC was busy (its last end - the launch's first start)
+    cu = (xcc << 8) | ((ids >> np.uint64(40)) & np.uint64(0xFF)).astype(np.int64)
+    sample = np.arange(0, rec.shape[0], max(1, rec.shape[0] // 200))
+    per_x = np.array([[int((xcc[l] == x).sum()) for x in range(8)] for l in sample])
+    cu_counts = [np.unique(cu[l], return_counts=True)[1] for l in sample]
+    t0l = start.min(axis=1)
+    busy = np.array([[(float(end[l][xcc[l] == x].max()) - float(t0l[l])) / 100.0 if (xcc[l] == x).any() else 0.0 for x in range(8)] for l in sample])
+    print(f"   workgroups per XCC (over {len(sample)} launches): min {per_x.min(axis=0).tolist()} max {per_x.max(axis=0).tolist()}   "
+          f"compute units used {int(np.median([len(c) for c in cu_counts]))}, workgroups per unit max {int(max(c.max() for c in cu_counts))} "
+          f"(median of the launches' maxima {int(np.median([c.max() for c in cu_counts]))})")
+    print("   per-XCC busy time us (median over launches): " + " ".join(f"{v:.1f}" for v in np.median(busy, axis=0)))
     nb = max(1, len(dur) // 100)
     series = [(float(begin[i * 100]), float(np.median(dur[i * 100:(i + 1) * 100])), float(dur[i * 100:(i + 1) * 100].max()),
                float(np.median(clk[i * 100:(i + 1) * 100])), float(clk[i * 100:(i + 1) * 100].min())) for i in range(nb)]
@@ -131,6 +143,10 @@ window("fresh0 (first serial frames of the process)")
 window("fresh1")
 window("fresh2")
 if SOAK_S <= 0:          # quick mode (A/B of kernel variants by cycles per launch): three windows, no soak
+    if os.environ.get("OCEAN_XCD_ROT_SWEEP"):       # developer build: which XCD writes which column group, rotated window by window
+        for rot in (1, 2, 3, 4, 5, 6, 0, 3, 0):
+            os.environ["OCEAN_XCD_ROT"] = str(rot)
+            window(f"rot{rot} (column groups of XCDs 1..7 rotated by {rot})", 2000)
     b.close(); child.terminate(); sys.exit(0)
 # ---- sustained load -------------------------------------------------------------------------------------------------------
 heavy = W.OceanBatch(2048, 1, 0); heavy.prepare(1); heavy.set_pipeline_depth(3)

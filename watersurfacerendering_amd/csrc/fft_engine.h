@@ -371,17 +371,19 @@ template <int N, class P, int MAXNS = 64> struct TwiddleTables {
     static constexpr int offset(int stage) { int o = 0; for (int s = 0; s < stage; ++s) if (has(s)) o += 7 * ns_of(s); return o; }
     static constexpr int total() { return offset(P::S); }          // float2 entries
     const c32* tab;
-    // every thread of the workgroup calls it; the caller's next barrier publishes the table
-    template <int STAGE = 1>
-    static __device__ __forceinline__ void build(c32* lds_tab, const c32* __restrict__ tw, int tid)
+    // Every thread of the workgroup calls it; the caller's next barrier publishes the table.  Row j % NS is built by thread j < NS from ITS OWN base
+    // twiddle of that stage (twr.w[STAGE][0] = tw[(j % NS) * N / (NS R)] with j = tid: a single-column batch, one butterfly per thread) -- no load
+    // of its own: a table load here sat, with its wait, in front of the workgroup's spectrum loads (+7 % on the whole kernel, round 6).
+    template <int STAGE = 1, class TWR>
+    static __device__ __forceinline__ void build(c32* lds_tab, const TWR& twr, int tid)
     {
         if constexpr (STAGE < P::S) {
             if constexpr (has(STAGE)) {
-                constexpr int NS = ns_of(STAGE), R = P::r[STAGE];
+                constexpr int NS = ns_of(STAGE);
                 if (tid < NS) {
                     typedef __attribute__((address_space(3))) v2 lds_v2;        // (explicitly LDS: ds_write, not flat stores)
                     v2 pw[5];
-                    pw[1] = tov(tw[tid * (N / (NS * R))]);
+                    pw[1] = tov(twr.w[STAGE][0]);
                     lds_v2* row = (lds_v2*)lds_tab + offset(STAGE) + tid;
                     row[0] = pw[1];
 #pragma unroll
@@ -390,7 +392,7 @@ template <int N, class P, int MAXNS = 64> struct TwiddleTables {
                     for (int i = 1; i < 4; ++i) row[(3 + i) * NS] = pk_cmul(pw[4], pw[i]);
                 }
             }
-            build<STAGE + 1>(lds_tab, tw, tid);
+            build<STAGE + 1>(lds_tab, twr, tid);
         }
     }
 };

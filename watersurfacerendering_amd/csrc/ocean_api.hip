@@ -11,6 +11,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #define OCEAN_INIT_KERNELS      // this translation unit also holds the Prepare() and consumer kernels
@@ -29,6 +30,27 @@ static thread_local int g_last_hip = 0;
             return e_ == hipErrorOutOfMemory ? OCEAN_E_NOMEM : OCEAN_E_HIP; \
         }                                               \
     } while (0)
+
+// Ranges page-locked through THIS library, with their device addresses (looked up once, at registration): ocean_compute_waves_read's copy
+// kernels store through them without asking the runtime on every call (hipHostGetDevicePointer costs a few microseconds of a 190 us call).
+// Memory page-locked by other means is still found, per call, through the runtime.  Process-wide like the registrations themselves; guarded.
+namespace {
+struct PinnedRange { char* host; size_t bytes; char* dev; };
+std::mutex g_pinned_mutex;
+std::vector<PinnedRange> g_pinned;
+void* pinned_device_address(const void* host_ptr, size_t bytes)
+{
+    const char* h = static_cast<const char*>(host_ptr);
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        for (const PinnedRange& r : g_pinned)
+            if (h >= r.host && h + bytes <= r.host + r.bytes) return r.dev + (h - r.host);
+    }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host_ptr), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dp;
+}
+}  // namespace
 
 static void free_set(ocean_ctx* c, int i);
 static void comm_release(ocean_ctx* c);
@@ -582,6 +604,10 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.mode = c->mode;
     a.start_ramp = 0;       // (set per launch by the launcher where a staggered start pays: ocean_launch.h)
     a.zmask = 15; a.xb_roles = 3;                   // (per launch: the launcher's frame order)
+    a.xcd_rot = 0;
+#ifdef OCEAN_DEVELOPER
+    if (const char* xr = getenv("OCEAN_XCD_ROT")) a.xcd_rot = atoi(xr) % 7;      // (read per frame: tools/xcd_rot.py flips it between windows)
+#endif
     a.rec_mode = track ? 2 : 1;                     // what the frame's LAST launch does with the completion records
     // maps beyond the memory-side cache, or several frames in flight: stream the maps past it
     const double texels = (double)c->tiles * (double)c->n * (double)c->n;
@@ -821,11 +847,10 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
     }
     // small maps into page-locked memory: a copy kernel (OceanTuning::copy_kernel_max_bytes); otherwise the runtime's copy
     bool by_kernel = bytes <= c->tune.copy_kernel_max_bytes;
-    void* dev_dst[2] = {nullptr, nullptr};        // (looked up per call: the caller may have unregistered the range since the last one)
+    void* dev_dst[2] = {nullptr, nullptr};        // (per call: ranges registered through ocean_host_register from the library's own list, others from the runtime)
     if (by_kernel) {
-        void* host[2] = {nrm, disp};
-        for (int k = 0; k < 2; ++k)
-            if (hipHostGetDevicePointer(&dev_dst[k], host[k], 0) != hipSuccess) { dev_dst[k] = nullptr; (void)hipGetLastError(); }
+        dev_dst[0] = pinned_device_address(nrm, bytes);
+        dev_dst[1] = pinned_device_address(disp, bytes);
         by_kernel = dev_dst[0] && dev_dst[1];
     }
     const size_t texels = bytes / sizeof(float4);
@@ -845,7 +870,8 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
         HIP_TRY(hipMemcpy(nrm, q, bytes, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(disp, d, bytes, hipMemcpyDeviceToHost));
     }
-    // the copies: polled like the records (a blocking synchronisation's wake-up costs 13-16 us per call), then -- long copies -- waited for
+    // the copies: polled like the records -- a blocking synchronisation's wake-up costs 13-16 us per call, and this call is the caller's
+    // whole frame (the reference's ComputeWaves keeps every core busy for its 44 ms) -- for up to 50 ms, then waited for
     using clock = std::chrono::steady_clock;
     const clock::time_point t0 = clock::now();
     for (int k = 0; k < 2; ++k) {
@@ -854,7 +880,7 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
             const hipError_t e = hipEventQuery(c->copy_done[k]);
             if (e == hipSuccess) break;
             if (e != hipErrorNotReady) { g_last_hip = (int)e; return OCEAN_E_HIP; }
-            if ((++spins & 63u) == 0 && clock::now() - t0 > std::chrono::milliseconds(1)) { HIP_TRY(hipEventSynchronize(c->copy_done[k])); break; }
+            if ((++spins & 255u) == 0 && clock::now() - t0 > std::chrono::milliseconds(50)) { HIP_TRY(hipEventSynchronize(c->copy_done[k])); break; }
             __builtin_ia32_pause();
         }
     }
@@ -868,12 +894,24 @@ int ocean_host_register(void* host_ptr, size_t bytes)
 {
     if (!host_ptr || bytes == 0) return OCEAN_E_INVALID;
     HIP_TRY(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, host_ptr, 0) == hipSuccess && dp) {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        g_pinned.push_back({static_cast<char*>(host_ptr), bytes, static_cast<char*>(dp)});
+    } else {
+        (void)hipGetLastError();
+    }
     return OCEAN_OK;
 }
 
 int ocean_host_unregister(void* host_ptr)
 {
     if (!host_ptr) return OCEAN_E_INVALID;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].host == host_ptr) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+    }
     HIP_TRY(hipHostUnregister(host_ptr));
     return OCEAN_OK;
 }

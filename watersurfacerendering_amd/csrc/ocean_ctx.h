@@ -40,9 +40,10 @@ struct OceanTuning {
     double ramp_rate_bytes_per_s = 5.5e12;
     // ... twice that for the x passes of PIPELINED frames, which run beside the same launches of the other chains (item 11: 9 us; now 9.9 / 9.1) ...
     double ramp_pipelined_x = 2.0;
-    // ... and only for launches that move at least this much: below it the bursts are too short to be worth a wait (1024^2, 23-29 MB per
-    // launch: z pass 14.5-15.3 -> 14.8-15.3, displacement pass 7.4-8.5 -> 8.2-9.8 us: a loss; 2048^2, 92-117 MB: -1 us per launch).
-    double ramp_min_bytes = 64.0e6;
+    // ... and only for launches over at least this many texels: below it the bursts are too short to be worth a wait (1024^2, 1 Mi texels:
+    // z pass 14.5-15.3 -> 14.8-15.3, displacement pass 7.4-8.5 -> 8.2-9.8 us: a loss; 2048^2, 4 Mi: -1 us per launch in every mode and precision,
+    // r04 item 12 -- which is why the bound is on texels, not bytes: the half2 / fp16-spectrum launches of a 2048^2 tile move 50 MB and gain too).
+    double ramp_min_texels = 4.0e6;
     // ... and whose resident round is at most this many workgroups per compute unit: a unit that is handed ten small workgroups staggers them by
     // itself, and a rule that trusted the occupancy query alone lost 12 % on serial 5 x 1024^2 frames (z pass 33 -> 39-43 us; 3 and 4 tiles:
     // -1 ... +1 %; round 6, profiles/r06_tuning_rules.txt).  The launches that gain hold 1-5 per unit.
@@ -69,7 +70,7 @@ inline void ocean_launch_bytes_per_texel(bool half_inter, bool jacobian, bool h0
 struct ocean_ctx {
     OceanTuning tune;               // the heuristics' constants (defaults above; nothing changes them at run time)
     int occ_n = 0;                  // tile size occ_* were asked for: resident workgroups per compute unit of the single-transform z pass and of
-    int occ_z = 0, occ_b = 0, occ_d = 0;    //   the two x passes on this device (hipOccupancyMaxActiveBlocksPerMultiprocessor; ocean_launch.h)
+    int occ_z = 0, occ_z_all = 0, occ_b = 0, occ_d = 0;    //   (both instantiations) and of the two x passes on this device (hipOccupancyMaxActiveBlocksPerMultiprocessor; ocean_launch.h)
     uint32_t n = 0;
     uint32_t tiles = 0;
     int device = 0;

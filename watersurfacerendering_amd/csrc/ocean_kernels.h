@@ -221,6 +221,8 @@ struct FrameArgs {
                              // {pair 1, pair 2} as two launches, each animating the spectrum for itself
     int xb_roles;            // k_xpass_b: bit 0 the HEIGHT workgroups, bit 1 the NORMAL workgroups (3 = both in one launch), bit 2 the DISP
                              // workgroups as well (7 = the merged x pass: the whole x axis in one launch, no k_xpass_disp)
+    int xcd_rot;             // developer builds only (OCEAN_XCD_ROT, tools/xcd_rot.py): the single-transform z pass hands the column groups of XCDs 1..7 round
+                             // by this many places -- which XCD writes which part of the intermediates -- 0 in the shipped library
     int rec_mode;            // completion records of this launch: 0 none, 1 block 0 writes them early (untracked frame: the stream tells when it
                              // has finished), 2 the last workgroup to finish writes them (frame_done; tracked frame) -- the frame's LAST launch
 };
@@ -1425,9 +1427,14 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     // the early stages' twiddle powers, once per workgroup for all four transforms (fft_engine.h: TwiddleTables); published by phase 1's barrier
     using TT = C1TwiddleTables<N, P>;
     c32* twtab = reinterpret_cast<c32*>(sp + N);
-    TT::build(twtab, a.tw, tid);
     const TT tt{twtab};
+    static_assert(TT::total() == 0 || (FirstStage<N, 1, T, P>::IT == 1 && T >= 64), "a table row per thread, from its own base twiddles");
+#ifdef OCEAN_DEVELOPER      // (experiment: XCD x > 0 takes the column group of XCD 1 + (x - 1 + rot) % 7; group 0 holds one column more and stays)
+    const int bxr = (blockIdx.x % 8 == 0 || a.xcd_rot == 0) ? (int)blockIdx.x : (int)(blockIdx.x / 8 * 8 + 1 + (blockIdx.x % 8 - 1 + a.xcd_rot) % 7);
+    const int nb = xcd_swizzle(bxr, N / 2 + 1);
+#else
     const int nb = xcd_swizzle((int)blockIdx.x, N / 2 + 1);     // neighbouring columns write neighbouring pieces of the same lines: same XCD, same L2
+#endif
     const float t = a.t + (a.toff ? a.toff[tile] : 0.0f);
     const float* __restrict__ k1 = a.k1d + (size_t)tile * N;
     const bool col0 = (nb == 0);
@@ -1447,6 +1454,7 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
 #pragma unroll
             for (int u = 0; u < PB; ++u)
                 zpass_load_pair<N, H16, W16, ZNT, PT>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
+            if (ub == 0) TT::build(twtab, twr, tid);      // (behind the loads' issue: its inputs are twiddle registers fetched ahead of them)
             if constexpr (PT) {
                 if (ub == 0) {          // the phase table, while the loads travel (see animate_with_phase)
                     for (unsigned q = (unsigned)tid; q <= a.wq_max; q += (unsigned)T) {

@@ -52,9 +52,9 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     const unsigned cus = (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
     // Staggered start (ocean_kernels.h: start_ramp_wait; the rule and its constants: OceanTuning, ocean_ctx.h).  A launch gets one when its WHOLE
     // grid is resident at once on this device -- grid <= compute units x resident workgroups per unit, the latter asked of the runtime for the
-    // kernels in question -- and it moves enough bytes for the bursts to be worth separating; the spread is a fraction of its expected duration.
+    // kernels in question -- and it covers enough texels for the bursts to be worth separating; the spread is a fraction of its expected duration.
     // In practice: the three launches of one 2048^2 tile (every mode and precision), 4.2 / 5.1 / 4.0 us serial, the x passes twice that when
-    // pipelined; not 1024^2 (too few bytes), not 4096^2 or batches (several rounds, which overlap by themselves).  ocean_set_start_ramp(ctx, 0)
+    // pipelined; not 1024^2 (too few texels), not 4096^2 or batches (several rounds, which overlap by themselves).  ocean_set_start_ramp(ctx, 0)
     // switches it off altogether (a device shared with other work: a workgroup's wait is simply lost).
     int ramp_z = 0, ramp_b = 0, ramp_d = 0;          // (computed below, once the kernels' attributes are set)
     // function attributes are per device; a context belongs to one device and one thread, so the flag
@@ -97,14 +97,17 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     }
     if (c->start_ramp && cus) {
         if (c->occ_n != N) {
-            int oz = 0, ob = 0, od = 0;
-            if constexpr (zpass_has_c1<N>())
+            int oz = 0, oza = 0, ob = 0, od = 0;
+            if constexpr (zpass_has_c1<N>()) {      // (the usual form of the spectrum and the instantiation that carries every form: different launch bounds)
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oz, k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, false, false, true>,
                                                                    zpass_c1_threads<N>(), zpass_c1_lds_bytes<N>());
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oza, k_zpass_c1<N, zpass_c1_threads<N>(), typename C1Plan<N>::type, false, false, false>,
+                                                                   zpass_c1_threads<N>(), zpass_c1_lds_bytes<N>());
+            }
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_xpass_b<N, C, G::T_C, typename G::PC, false, false, false>, G::T_C, lds_b);
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&od, k_xpass_disp<N, C, G::T_C, typename G::PC, false, false, false>, G::T_C, lds_m);
             (void)hipGetLastError();
-            c->occ_z = oz; c->occ_b = ob; c->occ_d = od; c->occ_n = N;
+            c->occ_z = oz; c->occ_z_all = oza; c->occ_b = ob; c->occ_d = od; c->occ_n = N;
         }
         int bpt[3];
         ocean_launch_bytes_per_texel((stream_maps & 8) != 0, a.mode == 3, a.h0h != nullptr, a.omega_q != nullptr, bpt);
@@ -113,11 +116,10 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
         auto ramp_ticks = [&](int bytes_per_texel, unsigned workgroups, int per_cu, double scale) -> int {
             const double bytes = texels * bytes_per_texel;
             const unsigned slots = (unsigned)per_cu < tu.ramp_max_wg_per_cu ? (unsigned)per_cu : tu.ramp_max_wg_per_cu;
-            if (per_cu <= 0 || workgroups > slots * cus || bytes < tu.ramp_min_bytes) return 0;
+            if (per_cu <= 0 || workgroups > slots * cus || texels < tu.ramp_min_texels) return 0;
             return (int)(tu.ramp_frac * scale * bytes / tu.ramp_rate_bytes_per_s * 1.0e8 + 0.5);      // 10 ns ticks (s_memrealtime)
         };
-        // (the instantiations that carry every form of the spectrum hold one workgroup per unit less: launch bounds 5 instead of 6 waves per SIMD)
-        ramp_z = ramp_ticks(bpt[0], (unsigned)(N / 2 + 1) * tiles, c->occ_z - (fast ? 0 : 1), 1.0);
+        ramp_z = ramp_ticks(bpt[0], (unsigned)(N / 2 + 1) * tiles, fast ? c->occ_z : c->occ_z_all, 1.0);
         // k_xpass_b: over its NORMAL workgroups and their bytes alone -- the height workgroups (2 B/texel in, 2 out) write next to nothing and all
         // start at once (item 10); the Jacobian mode's few workgroups beyond one round do not change the picture (item 12: same gain)
         ramp_b = ramp_ticks(bpt[1] - 4, (hb_b + nb) * tiles, c->occ_b, alone ? 1.0 : tu.ramp_pipelined_x);
