@@ -14,7 +14,8 @@ def plans_from_sources():
     for n, radices in re.findall(r"struct Plan<(\d+)>\s*:\s*Radices<([\d,\s]+)>", eng):
         plans.setdefault(int(n), []).append([int(r) for r in radices.split(",")])
     ker = open(os.path.join(CSRC, "ocean_kernels.h")).read()
-    for n, radices in re.findall(r"struct HalfHeightPlan<(\d+)>\s*:\s*Radices<([\d,\s]+)>", ker):      # the N/2-point transform of the real height column
+    exp = os.path.join(CSRC, "experimental", "zpass_half_height.h")                  # (developer builds only: round 5's experiment)
+    for n, radices in re.findall(r"struct HalfHeightPlan<(\d+)>\s*:\s*Radices<([\d,\s]+)>", open(exp).read() if os.path.exists(exp) else ""):      # the N/2-point transform of the real height column
         plans.setdefault(int(n) // 2, []).append([int(r) for r in radices.split(",")])
     for n, args in re.findall(r"^OCEAN_GEO\((\d+),(.*)\)\s*$", ker, flags=re.M):
         for radices in re.findall(r"OCEAN_R\(([\d,\s]+)\)", args):

@@ -353,72 +353,13 @@ template <int N, int C, int T, class P, int LM = 0> struct TwiddleRegs {
     template <int TS> __device__ __forceinline__ void load_strided(const c32* __restrict__ tw, int tid) { load_from<0, 1, TS>(tw, tid); }
 };
 
-// Twiddle-power tables in LDS (round 6).  A radix-8 butterfly of a twiddled stage multiplies its legs by w1^k, k = 1..7, built from the base
-// twiddle by six products -- twelve of its 26 twiddle instructions -- and a workgroup that runs several transforms one after the other (the
-// single-transform z pass: four per column) builds the same powers again for every one of them: holding them in registers across transforms
-// costs the occupancy (batch_fft launders the base twiddles for that reason).  The multipliers depend on j % NS alone, so for the early stages
-// (NS <= 64) they fit a small table -- NS rows of 7 -- that the workgroup builds ONCE, each row by the very chain apply_twiddles runs (the same
-// instructions on the same table entry: the same bits), and every transform reads: 7 ds_read_b64 instead of 12 vector instructions per
-// butterfly.  Layout [k - 1][j % NS]: the lanes of a read hold consecutive j, hence consecutive words.
-struct NoTwiddleTables {
-    static constexpr bool has(int) { return false; }
-    static constexpr int offset(int) { return 0; }
-};
-// MAXNS: the stages tabulated are the radix-8 ones with 1 < NS <= MAXNS (64: 504 entries = 4 KB; 8: 56 entries)
-template <int N, class P, int MAXNS = 64> struct TwiddleTables {
-    static constexpr int ns_of(int stage) { int ns = 1; for (int s = 0; s < stage; ++s) ns *= P::r[s]; return ns; }
-    static constexpr bool has(int stage) { return stage > 0 && stage < P::S && P::r[stage] == 8 && ns_of(stage) <= MAXNS; }
-    static constexpr int offset(int stage) { int o = 0; for (int s = 0; s < stage; ++s) if (has(s)) o += 7 * ns_of(s); return o; }
-    static constexpr int total() { return offset(P::S); }          // float2 entries
-    const c32* tab;
-    // Every thread of the workgroup calls it; the caller's next barrier publishes the table.  Row j % NS is built by thread j < NS from ITS OWN base
-    // twiddle of that stage (twr.w[STAGE][0] = tw[(j % NS) * N / (NS R)] with j = tid: a single-column batch, one butterfly per thread) -- no load
-    // of its own: a table load here sat, with its wait, in front of the workgroup's spectrum loads (+7 % on the whole kernel, round 6).
-    template <int STAGE = 1, class TWR>
-    static __device__ __forceinline__ void build(c32* lds_tab, const TWR& twr, int tid)
-    {
-        if constexpr (STAGE < P::S) {
-            if constexpr (has(STAGE)) {
-                constexpr int NS = ns_of(STAGE);
-                if (tid < NS) {
-                    typedef __attribute__((address_space(3))) v2 lds_v2;        // (explicitly LDS: ds_write, not flat stores)
-                    v2 pw[5];
-                    pw[1] = tov(twr.w[STAGE][0]);
-                    lds_v2* row = (lds_v2*)lds_tab + offset(STAGE) + tid;
-                    row[0] = pw[1];
-#pragma unroll
-                    for (int i = 2; i <= 4; ++i) { pw[i] = pk_cmul(pw[i / 2], pw[i - i / 2]); row[(i - 1) * NS] = pw[i]; }
-#pragma unroll
-                    for (int i = 1; i < 4; ++i) row[(3 + i) * NS] = pk_cmul(pw[4], pw[i]);
-                }
-            }
-            build<STAGE + 1>(lds_tab, twr, tid);
-        }
-    }
-};
-
 // One Stockham stage over the whole batch.
 //   FIRST: inputs from in(idx, c, u, i) (u, i are unrolled constants: the functor may
 //          serve values it prefetched into registers);  otherwise from LDS
 //   LAST : outputs to out(idx, c, value, u, i) (u, i are unrolled constants);
 //          otherwise to LDS, in place (reads complete -> barrier -> writes)
-// x[k] *= (row j % NS of the stage's table)[k], or the chain of apply_twiddles
-template <int R, int NS, int STAGE, class TT>
-__device__ __forceinline__ void stage_twiddles(v2 (&x)[R], v2 w1, const TT& tt, int j)
-{
-    if constexpr (TT::has(STAGE)) {
-        static_assert(R == 8, "tables hold radix-8 stages");
-        typedef __attribute__((address_space(3))) const v2 lds_cv2;             // (explicitly LDS: ds_read, not flat loads)
-        const lds_cv2* row = (const lds_cv2*)tt.tab + TT::offset(STAGE) + (j % NS);
-#pragma unroll
-        for (int k = 1; k < R; ++k) x[k] = pk_cmul(x[k], row[(k - 1) * NS]);
-    } else {
-        apply_twiddles<R>(x, w1);
-    }
-}
-
-template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, bool WRM, int NSR, class TW, class In, class Out, class TT>
-__device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& in, Out& out, const TT& tt)
+template <int N, int R, int NS, int C, int T, bool FIRST, bool LAST, int STAGE, int LM, bool WRM, int NSR, class TW, class In, class Out>
+__device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
     // NSR: the NS of the stage that wrote the image this stage reads (lds_index_x: per-exchange layouts of single-column batches)
     // WRM: this stage's outputs feed the last stage of a batch whose last exchange is row-major (lds_row_major_last)
@@ -450,7 +391,7 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
                     else x[i] = ldsv[rb + lds_delta_x<C, NSR, N>(i * (N / R))];
                 }
 #ifndef OCEAN_ABL_NOFFT
-                if constexpr (NS > 1) stage_twiddles<R, NS, STAGE>(x, tov(twr.w[STAGE][u]), tt, j);
+                if constexpr (NS > 1) apply_twiddles<R>(x, tov(twr.w[STAGE][u]));
                 Dft<R>::run(x);
 #endif
                 const int k = j % NS;
@@ -476,7 +417,7 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
                 else x[u][i] = ldsv[rb + lds_delta_x<C, NSR, N>(i * (N / R))];
             }
 #ifndef OCEAN_ABL_NOFFT
-            if constexpr (NS > 1) stage_twiddles<R, NS, STAGE>(x[u], tov(twr.w[STAGE][u]), tt, j);
+            if constexpr (NS > 1) apply_twiddles<R>(x[u], tov(twr.w[STAGE][u]));
             Dft<R>::run(x[u]);
 #endif
         }
@@ -498,18 +439,18 @@ __device__ __forceinline__ void fft_stage(c32* lds, const TW& twr, int tid, In& 
     }
 }
 
-template <int N, int C, int T, class P, int STAGE, int NS, int LM, class TW, class In, class Out, class TT>
-__device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In& in, Out& out, const TT& tt)
+template <int N, int C, int T, class P, int STAGE, int NS, int LM, class TW, class In, class Out>
+__device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In& in, Out& out)
 {
     constexpr int R = P::r[STAGE];
     constexpr int NSR = STAGE == 0 ? 1 : NS / P::r[STAGE == 0 ? 0 : STAGE - 1];      // the NS of the stage before this one
     constexpr bool FIRST = STAGE == 0, LAST = STAGE == P::S - 1;
     constexpr bool WRM = STAGE == P::S - 2 && lds_row_major_last<N, C, LM, P::last>();
-    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM, WRM, NSR>(lds, twr, tid, in, out, tt);
+    fft_stage<N, R, NS, C, T, FIRST, LAST, STAGE, LM, WRM, NSR>(lds, twr, tid, in, out);
     OCEAN_STAMP(10 + 3 * STAGE);
     if constexpr (!LAST) {
         __syncthreads();
-        run_stages<N, C, T, P, STAGE + 1, NS * R, LM>(lds, twr, tid, in, out, tt);
+        run_stages<N, C, T, P, STAGE + 1, NS * R, LM>(lds, twr, tid, in, out);
     }
 }
 
@@ -518,9 +459,8 @@ __device__ __forceinline__ void run_stages(c32* lds, const TW& twr, int tid, In&
 // `twr` = TwiddleRegs<N, C, T, P> loaded from the table tw[k] = exp(+2 pi i k / N).
 // The call may start while other waves still read `lds` from a previous call:
 // the first LDS write is preceded by a barrier.
-// tt: twiddle-power tables of the early stages (TwiddleTables; default: none, every butterfly builds its powers from the base twiddle)
-template <int N, int C, int T, class P = Plan<N>, int LM = 0, class In, class Out, class TT = NoTwiddleTables>
-__device__ __forceinline__ void batch_fft(c32* lds, TwiddleRegs<N, C, T, P, LM>& twr, int tid, In& in, Out& out, const TT& tt = TT{})
+template <int N, int C, int T, class P = Plan<N>, int LM = 0, class In, class Out>
+__device__ __forceinline__ void batch_fft(c32* lds, TwiddleRegs<N, C, T, P, LM>& twr, int tid, In& in, Out& out)
 {
     static_assert(P::product() == N, "radix plan does not match the transform length");
     // Launder the base twiddles: otherwise the compiler hoists the whole power chain
@@ -533,7 +473,7 @@ __device__ __forceinline__ void batch_fft(c32* lds, TwiddleRegs<N, C, T, P, LM>&
 #pragma unroll
         for (int u = 0; u < TwiddleRegs<N, C, T, P, LM>::it_of(s); ++u)
             asm volatile("" : "+v"(twr.w[s][u].x), "+v"(twr.w[s][u].y));
-    run_stages<N, C, T, P, 0, 1, LM>(lds, twr, tid, in, out, tt);
+    run_stages<N, C, T, P, 0, 1, LM>(lds, twr, tid, in, out);
 }
 
 // Mapping of the FIRST stage: work item w = tid + u*T reads inputs

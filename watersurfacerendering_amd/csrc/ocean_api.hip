@@ -14,8 +14,8 @@
 #include <mutex>
 #include <vector>
 
-#define OCEAN_INIT_KERNELS      // this translation unit also holds the Prepare() and consumer kernels
 #include "ocean_ctx.h"
+#include "ocean_aux_kernels.h"      // this translation unit also holds the Prepare(), read-out and consumer kernels
 
 using namespace ocean;
 
@@ -156,7 +156,7 @@ static int alloc_device(ocean_ctx* c)
     HIP_TRY(hipMalloc(&c->omega, t * n2 * sizeof(float)));
     HIP_TRY(hipMalloc(&c->omega_q, t * n2 * sizeof(uint16_t)));
     HIP_TRY(hipMalloc(&c->base_freq, t * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->omega_q_overflow, 2 * sizeof(unsigned)));      // [0] some multiple needs more than 16 bits, [1] the largest multiple
+    HIP_TRY(hipMalloc(&c->omega_q_overflow, sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->k1d, t * n * sizeof(float)));
     HIP_TRY(hipMalloc(&c->tw, n * sizeof(float2)));
     {
@@ -435,7 +435,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
         dim3 g((unsigned)((n + 255) / 256), (unsigned)t);
         hipLaunchKernelGGL(k_init_k1d, g, dim3(256), 0, stream_of(c, 0), c->k1d, c->tparams, (int)n);
         dim3 g2((unsigned)((n2 + 255) / 256), (unsigned)t);
-        HIP_TRY(hipMemsetAsync(c->omega_q_overflow, 0, 2 * sizeof(unsigned), stream_of(c, 0)));
+        HIP_TRY(hipMemsetAsync(c->omega_q_overflow, 0, sizeof(unsigned), stream_of(c, 0)));
         hipLaunchKernelGGL(k_init_spectrum, g2, dim3(256), 0, stream_of(c, 0), c->h0, c->omega, c->omega_q, c->base_freq, c->omega_q_overflow,
                            xi_or_null ? (float2*)nullptr : c->xi, xi_or_null ? c->xi : (const float2*)nullptr,
                            c->k1d, c->tparams, (int)n);
@@ -504,10 +504,9 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     }
     SYNC_ALL(c);
     {
-        unsigned ow[2] = {1u, 0xFFFFu};
-        HIP_TRY(hipMemcpy(ow, c->omega_q_overflow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
-        c->omega16 = ow[0] == 0;
-        c->wq_max = ow[1];
+        unsigned overflow = 1;
+        HIP_TRY(hipMemcpy(&overflow, c->omega_q_overflow, sizeof(unsigned), hipMemcpyDeviceToHost));
+        c->omega16 = overflow == 0;
 #ifdef OCEAN_DEVELOPER      // A/B builds only (make variant ... DEFS=-DOCEAN_DEVELOPER): the shipped library reads no environment
         static const char* const w16_env = getenv("OCEAN_OMEGA16");
         if (w16_env && atoi(w16_env) == 0) c->omega16 = false;
@@ -565,7 +564,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     }
     FrameArgs a;
     a.h0 = c->h0; a.omega = c->omega; a.k1d = c->k1d; a.tw = c->tw;
-    a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq; a.wq_max = c->wq_max;
+    a.omega_q = c->omega16 ? c->omega_q : nullptr; a.base_freq = c->base_freq;
     a.h0h = (c->h0_bits == 16) ? c->h0h : nullptr; a.h0_inv_scale = c->h0_inv_scale;
     a.zscale = c->zscale;
     a.z = c->z[set]; a.zh = c->zh[set]; a.hraw = c->hraw[set]; a.minmax = c->minmax[set]; a.hdone = c->hdone[set];

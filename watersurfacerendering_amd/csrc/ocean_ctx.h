@@ -104,7 +104,6 @@ struct ocean_ctx {
     float* base_freq = nullptr;     // [tiles]
     unsigned* omega_q_overflow = nullptr;
     bool omega16 = false;           // every multiple fits 16 bits (decided at ocean_prepare)
-    unsigned wq_max = 0xFFFFu;      // the largest of them over all tiles (FrameArgs::wq_max: the size of the z pass's phase table)
     float* k1d = nullptr;
     float2* tw = nullptr;
     float2* z[MAXD] = {};

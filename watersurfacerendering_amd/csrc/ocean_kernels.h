@@ -175,8 +175,6 @@ struct FrameArgs {
     const float* omega;      // [tiles][N][N]   quantised dispersion, same layout
     const uint16_t* omega_q; // [tiles][N][N]   the same as the integer multiple of base_freq (null: use omega); see k_zpass
     const float* base_freq;  // [tiles]
-    unsigned wq_max;         // largest 16-bit multiple in omega_q over all tiles of the context (k_init_spectrum): the phase table of the
-                             // single-transform z pass has wq_max + 1 entries (k_zpass_c1, FAST)
     const __half2* h0h;      // [tiles][N][N]   optional fp16 copy of h0 scaled by 1/h0_inv_scale[tile] (null = fp32)
     const float* h0_inv_scale;   // [tiles]
     const float* k1d;        // [tiles][N]      k(i) = float(pi*(2i-N)/L)
@@ -242,174 +240,6 @@ __host__ __device__ inline float key_float(unsigned k)
     return v.f;
 }
 
-#ifdef OCEAN_INIT_KERNELS
-// ============================================================================
-// Prepare(): wave vectors (.cpp:60-85), gaussian draws (.cpp:87-103, RNG
-// replaced by a counter-based one), base spectrum + dispersion (.cpp:105-148).
-// No FMA contraction here: omega goes through floor() and must match the fp32
-// evaluation order of the reference.
-// ============================================================================
-__device__ inline uint64_t splitmix64(uint64_t seed, uint64_t idx)
-{
-    uint64_t z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-__device__ inline float2 gauss_pair(uint64_t seed, uint64_t idx)
-{
-    const uint64_t z = splitmix64(seed, idx);
-    const double u1 = ((double)(z >> 40) + 1.0) * (1.0 / 16777216.0);
-    const double u2 = (double)((z >> 8) & 0xFFFFFFull) * (1.0 / 16777216.0);
-    const double r = sqrt(-2.0 * log(u1));
-    const double a = 6.283185307179586476925286766559 * u2;
-    double s, c;
-    sincos(a, &s, &c);
-    return make_float2((float)(r * c), (float)(r * s));
-}
-
-__global__ void k_init_k1d(float* __restrict__ k1d, const TileParams* __restrict__ tp, int n)
-{
-    const int tile = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // M_PI * (2.0f*i - kSize) / kLength : float numerator, double product/quotient (.cpp:76-79)
-    const float num = 2.0f * (float)i - (float)n;
-    k1d[(size_t)tile * n + i] =
-        (float)(3.14159265358979323846 * (double)num / (double)tp[tile].length);
-}
-
-__device__ inline float phillips_nc(const TileParams& p, float ux, float uz, float k)
-{
-#pragma clang fp contract(off)
-    // WSTessendorf.h:249-263
-    const float k2 = k * k;
-    const float k4 = k2 * k2;
-    float cf = ux * p.wind_x + uz * p.wind_y;
-    cf = cf * cf;
-    const float lw = p.wind_speed * p.wind_speed / 9.81f;
-    const float l2 = lw * lw;
-    return p.phillips_a * expf(-1.0f / (k2 * l2)) / k4 * cf * expf(-k2 * p.damping * p.damping);
-}
-
-__global__ void k_init_spectrum(float2* __restrict__ h0, float* __restrict__ omega, uint16_t* __restrict__ omega_q,
-                                float* __restrict__ base_freq, unsigned* __restrict__ omega_q_overflow, float2* __restrict__ xi_out,
-                                const float2* __restrict__ xi_in, const float* __restrict__ k1d,
-                                const TileParams* __restrict__ tp, int n)
-{
-#pragma clang fp contract(off)
-    const int tile = blockIdx.y;
-    const size_t n2 = (size_t)n * n;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2) return;
-    const TileParams p = tp[tile];
-    // the spectrum is stored TRANSPOSED: element i holds wave index (m, q) = (i % n, i / n),
-    // so that a spectrum column (fixed kx) is one contiguous run for the first pass.
-    // The gaussian draw of texel (m, q) keeps the reference's row-major index m*n + q.
-    const int q = (int)(i / n), m = (int)(i % n);
-    const size_t ref = (size_t)m * n + q;
-    const float kx = k1d[(size_t)tile * n + q], kz = k1d[(size_t)tile * n + m];
-    const float d = kx * kx + kz * kz;
-    const float k = sqrtf(d);
-    const float2 g = xi_in ? xi_in[tile * n2 + ref] : gauss_pair(p.seed, ref);
-    if (xi_out) xi_out[tile * n2 + ref] = g;
-    float2 a = make_float2(0.f, 0.f);
-    float w = 0.f, steps = 0.f;
-    if (i == 0) base_freq[tile] = p.base_freq;
-    if (k > 0.00001f) {
-        const float inv = 1.0f / sqrtf(d);            // glm::normalize (.h:133-136)
-        const float ux = kx * inv, uz = kz * inv;
-        const float sp = sqrtf(phillips_nc(p, ux, uz, k));
-        const float s = 1.0f / sqrtf(2.0f);
-        a.x = (s * g.x) * sp;                         // .h:237-243
-        a.y = (s * g.y) * sp;
-        float disp;                                   // the relation the reference calls, or one of the two it only defines
-        if (p.dispersion == 1)        // sqrt(g k tanh(k D)): in double, rounded once (tanhf differs between libms)
-            disp = (float)sqrt((double)(9.81f * k) * tanh((double)k * (double)p.dispersion_param));
-        else if (p.dispersion == 2)   // sqrt(g k (1 + k^2 L^2))
-            disp = sqrtf(9.81f * k * (1.0f + k * k * p.dispersion_param * p.dispersion_param));
-        else
-            disp = sqrtf(9.81f * k);
-        steps = floorf(disp / p.base_freq);
-        w = steps * p.base_freq;                         // .h:284-287
-    }
-    h0[tile * n2 + i] = a;
-    omega[tile * n2 + i] = w;
-    // omega is an integer multiple of base_freq: the frame kernels read that integer (2 bytes instead of
-    // 4 per texel) and rebuild the same float, float(steps) * base_freq, unless some multiple needs more bits
-    omega_q[tile * n2 + i] = (uint16_t)(steps < 65536.0f ? (unsigned)steps : 0u);
-    if (!(steps < 65536.0f)) atomicOr(omega_q_overflow, 1u);
-    // [1]: the largest multiple (one atomic per wave): the size of the z pass's per-frame phase table
-    unsigned mq = steps < 65536.0f ? (unsigned)steps : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned other = (unsigned)__shfl_xor((int)mq, o); mq = other > mq ? other : mq; }
-    if ((threadIdx.x & 63) == 0) atomicMax(omega_q_overflow + 1, mq);
-}
-
-// fp16 spectrum variant (BASELINE config 4): h0 stored as half2 scaled per tile so
-// that max|component| maps to 2^14 (keeps the small amplitudes normal numbers).
-__global__ void k_h0_absmax(const float2* __restrict__ h0, unsigned* __restrict__ maxbits, size_t n2)
-{
-    const int tile = blockIdx.y;
-    float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        const float2 v = h0[tile * n2 + i];
-        m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(maxbits + tile, __float_as_uint(m));   // non-negative floats order like uints
-}
-
-__global__ void k_h0_to_half(const float2* __restrict__ h0, __half2* __restrict__ h0h, const unsigned* __restrict__ maxbits,
-                             float* __restrict__ inv_scale, size_t n2)
-{
-    const int tile = blockIdx.y;
-    const float m = __uint_as_float(maxbits[tile]);
-    // power-of-two scale: exact to apply and to undo
-    int e = 0;
-    if (m > 0.0f) (void)frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
-    const float scale = ldexpf(1.0f, 14 - e);
-    if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[tile] = ldexpf(1.0f, e - 14);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        const float2 v = h0[tile * n2 + i];
-        h0h[tile * n2 + i] = __floats2half2_rn(v.x * scale, v.y * scale);
-    }
-}
-
-// Bounds for the half2 intermediates (ocean_set_intermediate_precision(16)), per tile, time independent:
-//   |h~(k, t)| <= 2 |h0(k)|, so every component of a z-pass output of spectrum column n is at most
-//   2 * sum_e |h0(e, n)| + 2 * sum_e |h0(e, -n)|   for the fields weighted by unit vectors (pair 0, height), and the same
-//   with |k| |h0| for the fields weighted by k (pairs 1 and 2).  One workgroup per spectrum column (contiguous in the
-//   transposed layout) sums |h0| and |k| |h0|; the maxima over the columns go to bounds[tile][0..1] as float bits.
-__global__ void k_inter_bounds(const float2* __restrict__ h0, const float* __restrict__ k1d, unsigned* __restrict__ bounds, int n)
-{
-    const int tile = blockIdx.y, col = blockIdx.x;
-    const float2* __restrict__ c = h0 + ((size_t)tile * n + col) * n;
-    const float* __restrict__ k1 = k1d + (size_t)tile * n;
-    const float kx = k1[col];
-    float su = 0.0f, sk = 0.0f;
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        const float2 v = c[e];
-        const float m = sqrtf(v.x * v.x + v.y * v.y), kz = k1[e];
-        su += m;
-        sk += m * sqrtf(kx * kx + kz * kz);
-    }
-    __shared__ float ru[16], rk[16];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { su += __shfl_xor(su, o); sk += __shfl_xor(sk, o); }
-    if ((threadIdx.x & 63) == 0) { ru[threadIdx.x >> 6] = su; rk[threadIdx.x >> 6] = sk; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tu = 0.0f, tk = 0.0f;
-        for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) { tu += ru[w]; tk += rk[w]; }
-        atomicMax(bounds + 2 * tile + 0, __float_as_uint(tu));      // non-negative floats order like uints
-        atomicMax(bounds + 2 * tile + 1, __float_as_uint(tk));
-    }
-}
-
-#endif  // OCEAN_INIT_KERNELS
 
 // ============================================================================
 // h~(k, t): WaveHeightFT (.h:265-275).  conj(h0(-k)) of the reference equals
@@ -490,8 +320,7 @@ template <int N, bool ZNT> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC
 #else
 template <int N, bool ZNT> constexpr bool spectrum_nt() { return N >= OCEAN_SPEC_NT_MIN && !ZNT; }
 #endif
-// RAWW (with W16, fp32 spectrum): w.x carries the two 16-bit multiples as loaded (bit pattern) -- the caller looks the phases up in a table
-template <int N, bool H16, bool W16, bool ZNT = false, bool RAWW = false>
+template <int N, bool H16, bool W16, bool ZNT = false>
 __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, int col, int n, float h16s, float base,
                                                 float4& ha, float2& hb0, float2& hb1, float2& w)
 {
@@ -513,8 +342,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
         const nt2 v0 = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(h0 + m0)), v1 = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(h0 + m1));
         ha = make_float4(va.x, va.y, va.z, va.w); hb0 = make_float2(v0.x, v0.y); hb1 = make_float2(v1.x, v1.y);
         const unsigned two = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g));
-        if constexpr (RAWW) w = make_float2(__uint_as_float(two), 0.0f);
-        else w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+        w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
         return;
     }
     if constexpr (H16) {
@@ -531,8 +359,7 @@ __device__ __forceinline__ void zpass_load_pair(const FrameArgs& a, int tile, in
     }
     if constexpr (W16) {      // two 16-bit multiples of base_freq -> the same two floats the fp32 array holds
         const unsigned two = *reinterpret_cast<const unsigned*>(a.omega_q + tile * n2 + g);
-        if constexpr (RAWW) w = make_float2(__uint_as_float(two), 0.0f);
-        else w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
+        w = make_float2(mul_nocontract((float)(two & 0xffffu), base), mul_nocontract((float)(two >> 16), base));
     } else {
         w = *reinterpret_cast<const float2*>(a.omega + tile * n2 + g);
     }
@@ -550,24 +377,6 @@ __device__ __forceinline__ void animate_with_mirror(float2 h0a, float2 h0b, floa
     av = height_re(h0a.x, h0a.y, c, s);
     bv = height_re(h0b.x, h0b.y, c, s);
 }
-
-// the same with the phase's (sin, cos) already known (the phase table of k_zpass_c1)
-__device__ __forceinline__ void animate_with_phase(float2 h0a, float2 h0b, float2 sc, float& av, float& bv)
-{
-    av = height_re(h0a.x, h0a.y, sc.y, sc.x);
-    bv = height_re(h0b.x, h0b.y, sc.y, sc.x);
-}
-// Phase table (round 6).  The dispersion is a 16-bit multiple q of the base frequency, so an element's phase is a function of q alone, and a
-// tile has few distinct q (301 at 2048^2 with the reference's defaults, 426 at 4096^2): every workgroup evaluates sincos ONCE per value --
-// entry q = sincos(fl(fl(q * base) * t)), the operations and the order of the per-element form (animate_with_mirror), hence the same bits --
-// into the FFT image's LDS, which is idle until the first exchange, while its spectrum loads are in flight; phase 1 then looks the elements
-// up.  One or two sincos per thread instead of eight: 160 vector instructions less per wave of 1 417 (profiles/r06_zpass_experiments.txt).
-// The table has FrameArgs::wq_max + 1 entries; the launcher falls back to the all-forms instantiation (per-element sincos) when that exceeds
-// the image (ocean_launch.h).
-#ifndef OCEAN_C1_PHASE_TABLE      // developer A/B: 0 = per-element sincos in every instantiation, as in rounds 2-5
-#define OCEAN_C1_PHASE_TABLE 1
-#endif
-template <int N> constexpr unsigned zpass_phase_table_capacity() { return (unsigned)fft_lds_elems<N, 1>() - 1u; }     // (the last slot carries S-(0))
 
 // ---- half-spectrum storage geometry -------------------------------------------
 #ifndef OCEAN_ZTILE
@@ -678,115 +487,13 @@ template <int N, int T, class P, int ZC, bool Z16> struct ZStore {
     }
 };
 
-// ---- the height's z-axis transform as a REAL-input transform (round 5; VERDICT r04 next #4: "3.5 transforms, not 4") ----------------------
-// S+ along a column is real, so its length-N transform Y(p) -- of which only p = 0 .. N/2 is kept, the rest being the conjugate -- is an
-// N/2-point COMPLEX transform of z(n) = S+(2n) + i S+(2n+1) followed by one split step:
-//     Z = B_{N/2}[z],   E(k) = (Z(k) + conj Z(M-k)) / 2,   O(k) = -i (Z(k) - conj Z(M-k)) / 2,   M = N/2,
-//     Y(k) = E(k) + w^k O(k),   Y(M-k) = conj(E(k) - w^k O(k)),   w = exp(+2 pi i / N),   k = 0 .. M/2  (indices mod M: k = 0 pairs with itself).
-// Half the butterflies and half the LDS traffic of the full-size transform whose upper half was thrown away, for one more exchange: the last
-// stage's outputs go, in natural order, into the S+ table -- nobody reads it any more, the height is the column's last batch -- and after a
-// barrier every thread takes the pairs k = t and k' = M/2 - t (w^k' = i conj(w^k): the same table entry with its parts swapped) and stores
-// the four rows t, M - t, M/2 - t, M/2 + t; thread 0 also takes k = M/4.  From 2048 points up, in the z-pass forms those tile sizes run
-// (single-transform batches; the two-column form of streamed intermediates at 2048) -- the SAME function in both, compiled without
-// contraction, so that the forms keep delivering the same bits.  The values differ from the full-size transform's in the last bits (other
-// butterflies, one rounding more in the split step): parity is against the oracle (1e-5 of the channel's maximum, measured 3e-7 like before).
-template <int N> struct HalfHeightPlan;                                   // radix plan of the N/2-point transform (tools/check_lds_offsets.py reads these)
-template <> struct HalfHeightPlan<2048> : Radices<8, 8, 4, 4> {};
-template <> struct HalfHeightPlan<4096> : Radices<8, 8, 8, 4> {};
-// MEASURED AND NOT ADOPTED (profiles/r05_zpass_experiments.txt): 2048^2 z pass 21.7-21.8 us either way, 4096^2 93.7-98.7 against 92.7-94.3 us
-// with the full-size transform -- the split step's extra exchange and barrier lengthen every workgroup's chain by about what the smaller
-// transform saves, and the z pass is bound by those chains, not by butterfly throughput.  The form stays selectable for developer builds
-// (make variant DEFS=-DOCEAN_HALF_HEIGHT_MIN=2048); the shipped library runs the full-size height transform at every size.
-#ifndef OCEAN_HALF_HEIGHT_MIN
-#define OCEAN_HALF_HEIGHT_MIN 8192
+// (Round 5's half-size real-input transform of the height -- built, measured, not adopted -- lives in experimental/zpass_half_height.h and is
+//  compiled only into developer builds that define OCEAN_HALF_HEIGHT_MIN.)
+#ifdef OCEAN_HALF_HEIGHT_MIN
+#include "experimental/zpass_half_height.h"
+#else
+template <int N> constexpr bool zpass_half_height() { return false; }
 #endif
-template <int N> constexpr bool zpass_half_height() { return N >= OCEAN_HALF_HEIGHT_MIN && N >= 2048; }
-
-__device__ __forceinline__ void real_split(c32 zk, c32 zm, c32 w, c32& yk, c32& ym)
-{
-#pragma clang fp contract(off)
-    const float ax = 0.5f * (zk.x + zm.x), ay = 0.5f * (zk.y - zm.y);       // E(k)
-    const float ox = 0.5f * (zk.y + zm.y), oy = -0.5f * (zk.x - zm.x);      // O(k)
-    const float bx = w.x * ox - w.y * oy, by = w.x * oy + w.y * ox;         // w^k O(k)
-    yk = make_float2(ax + bx, ay + by);
-    ym = make_float2(ax - bx, -(ay - by));
-}
-
-// C columns (c1 form: 1; two-column form: 2) by the T threads of the workgroup.  spx[c]: column c's S+ table [N floats] = the exchange's M
-// complex slots; splus(e, c): S+ of element e of column c (read from that table -- or formed from G on the Nyquist column).  A thread's
-// split items (column c, pair t) are the (c, j) of its last-stage work items: wk[u] = w^t = exp(+2 pi i t / N) of item u comes from the
-// caller -- it IS the full-size plan's last-stage base twiddle of the same thread where the forms below say so, a table entry otherwise.
-template <int N, int T, int C, bool ZNT, bool Z16, class TWH, class Splus>
-__device__ __forceinline__ void zpass_height_half(const FrameArgs& a, c32* fbuf, float* const (&spx)[C], TWH& twh,
-                                                  const c32 (&wk)[(C * (N / 8) + T - 1) / T], int tid, float2* __restrict__ zh,
-                                                  const int (&cols)[C], float su, Splus&& splus)
-{
-    using HF = Half<N>;
-    using PH = HalfHeightPlan<N>;
-    using LSH = LastStage<N / 2, C, T, PH>;
-    constexpr int M = N / 2, Q = M / 4;                    // Q pairs (k, k') per column
-    static_assert(PH::last == 4 && LSH::ITEMS == C * Q, "one split item per last-stage work item");
-    auto in = [&](int n, int c, int, int) -> c32 { return make_float2(splus(2 * n, c), splus(2 * n + 1, c)); };
-    auto out = [&](int p, int c, c32 v, int, int) { reinterpret_cast<c32*>(spx[c])[p] = v; };
-    batch_fft<M, C, T, PH>(fbuf, twh, tid, in, out);
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < LSH::IT; ++u) {
-        const int w = tid + u * T;
-        if (!LSH::GUARD || w < LSH::ITEMS) {
-            int c, t;
-            LSH::map(w, c, t);
-            const c32* __restrict__ zx = reinterpret_cast<const c32*>(spx[c]);
-            const int col = cols[c];
-            c32 y0, y1;
-            real_split(zx[t], zx[(M - t) & (M - 1)], wk[u], y0, y1);                         // k = t: rows t and M - t
-            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, t), y0, su);
-            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M - t), y1, su);
-            real_split(zx[M / 2 - t], zx[M / 2 + t], make_float2(wk[u].y, wk[u].x), y0, y1);  // k' = M/2 - t: rows M/2 - t and M/2 + t
-            store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 2 - t), y0, su);
-            if (t != 0) store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 2 + t), y1, su);
-            if (t == 0) {                                                                      // k = M/4: w^(N/8) = (1 + i) / sqrt 2
-                real_split(zx[M / 4], zx[3 * M / 4], make_float2(0.70710678118654752440f, 0.70710678118654752440f), y0, y1);
-                store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, M / 4), y0, su);
-                store_z<ZNT, Z16>(zh, HF::template zhidx<Z16>(col, 3 * M / 4), y1, su);
-            }
-        }
-    }
-}
-// The twiddle registers of that transform and w^t of the split step.  A thread's base twiddle of a stage is exp(+2 pi i (j % NS) / (NS R)):
-// the half-size plans run the tile size's own first stages, so where a stage of theirs has the NS of the full-size plan's stage it is that
-// stage's register (same radix) or its square (half the radix), with no load at all -- a load here sits on every workgroup's critical path,
-// and a single resident round (2048^2) is as long as its workgroups' chains:
-//     2048: full 8.8.8.4 (NS 1, 8, 64, 512), half 8.8.4.4 (NS 1, 8, 64, 256):  w1 = W1, w2 = W2^2, w3 = W3^2 (j < 256), w^t = W3
-//     4096: full 8.8.8.8 (NS 1, 8, 64, 512), half 8.8.8.4 (NS 1, 8, 64, 512):  w1 = W1, w2 = W2,   w3 = W3^2,           w^t = W3
-// for the forms whose work-item mapping the half-size transform shares (single-transform batches; the two-column form, whose first
-// last-stage item is the half-size one's).  from_table: the general way (the lone columns of the two-column kernel).
-template <int N, int T, int C> struct HalfHeightTwiddles {
-    using type = TwiddleRegs<N / 2, C, T, HalfHeightPlan<N>>;
-    static constexpr int ITW = (C * (N / 8) + T - 1) / T;
-    template <class TWF>
-    static __device__ __forceinline__ void from_full(const TWF& full, type& h, c32 (&wk)[ITW])
-    {
-        static_assert(ITW == 1 && (N == 2048 || N == 4096), "forms with one split item per thread");
-        h.w[0][0] = make_float2(1.f, 0.f);
-        h.w[1][0] = full.w[1][0];
-        // (squares through the packed multiply: instructions of their own, the same bits in every kernel that derives them)
-        h.w[2][0] = N == 2048 ? toc(pk_cmul(tov(full.w[2][0]), tov(full.w[2][0]))) : full.w[2][0];
-        h.w[3][0] = toc(pk_cmul(tov(full.w[3][0]), tov(full.w[3][0])));
-        wk[0] = full.w[3][0];
-    }
-    static __device__ __forceinline__ void from_table(const c32* __restrict__ tw, int tid, type& h, c32 (&wk)[ITW])
-    {
-        using LSH = LastStage<N / 2, C, T, HalfHeightPlan<N>>;
-        h.template load_strided<2>(tw, tid);
-#pragma unroll
-        for (int u = 0; u < ITW; ++u) {
-            int c, t;
-            LSH::map((tid + u * T) < LSH::ITEMS ? tid + u * T : 0, c, t);
-            wk[u] = tw[t];
-        }
-    }
-};
 
 // The four z-axis transforms of one spectrum column (see k_zpass).  COL0 = Nyquist
 // column nb == 0, the only one where Tx = S- along the whole column.
@@ -961,6 +668,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
         };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
         OCEAN_STAMP(3);
+#ifdef OCEAN_HALF_HEIGHT_MIN
         if constexpr (zpass_half_height<N>()) {
             // from 2048 points up every form of the z pass computes the height as a real-input transform (zpass_height_half), so that a
             // column's bits do not depend on the form that happened to run it (here: the lone columns 0, 1 and N/2 of the two-column kernel)
@@ -976,6 +684,7 @@ __device__ __forceinline__ void zpass_transforms(const FrameArgs& a, c32* fbuf, 
                                                       [&](int e, int) { asm("" : "+v"(e)); float sv, tx, tz; fetch(e, sv, tx, tz); return sv; });
             }
         }
+#endif
     }
     }
 }
@@ -1079,6 +788,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
         auto out = [&](int p, int c, c32 v, int u, int i) { store_z<ZNT, Z16>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb0 + c, p, u, i), v, sk); };
         batch_fft<N, 2, T, P>(fbuf, twr, tid, in, out);
     }
+#ifdef OCEAN_HALF_HEIGHT_MIN
     if constexpr (zpass_half_height<N>()) {
         if ((a.zmask & 8) && !jac) {      // both columns' heights as real-input transforms (zpass_height_half: the single-transform form's bits)
             using HT = HalfHeightTwiddles<N, T, 2>;
@@ -1091,6 +801,7 @@ __device__ __forceinline__ void zpass_two_columns(const FrameArgs& a, unsigned c
             return;
         }
     }
+#endif
     if (a.zmask & 8) {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
         auto in = [&](int e, int c, int, int i) -> c32 {
             float sv, tz, kx, kx2; fetch(e, c, sv, tz, kx, kx2);
@@ -1297,10 +1008,9 @@ struct ClockProbe {
 // workgroups per CU, the same number of waves, and each one's load burst and store tail travel under the other's transforms.  Same radix
 // plan, same inputs (zpass_input), same twiddles: bit-identical to the other forms (tests/test_variants_gpu.py).
 // ============================================================================
-template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false, class TT = NoTwiddleTables>
+template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false>
 __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float (&kzr)[P::r[0]],
-                                                        TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb,
-                                                        const TT& tt = TT{})
+                                                        TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb)
 {
     using HF = Half<N>;
     // kz of the first stage's inputs: thread j reads elements j + i * (N / R0), i = 0 .. R0-1, in every one of the four batches -- the
@@ -1342,7 +1052,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, zo.pos(nb, p, u, i), v, su); };
-            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
             auto in = [&](int e, int, int, int i) -> c32 {
@@ -1350,7 +1060,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
     }
     if ((a.mode == 0 || a.mode == 3) && (a.zmask & 4)) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
@@ -1359,8 +1069,9 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
         };
         auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
+#ifdef OCEAN_HALF_HEIGHT_MIN
     if constexpr (zpass_half_height<N>()) {
         if ((a.zmask & 8) && !jac) {      // the height as a real-input transform: half the size + one split step (zpass_height_half)
             using HT = HalfHeightTwiddles<N, T, 1>;
@@ -1378,6 +1089,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return;
         }
     }
+#endif
     if (a.zmask & 8) {   // height (or pair 3 = (height, cross derivative) of the Jacobian mode)
         auto in = [&](int e, int, int, int i) -> c32 {
             float sv, tx, tz, tc; fetch(e, sv, tx, tz, tc);
@@ -1388,23 +1100,13 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             if (jac) store_z<ZNT, Z16, ZWT>(z3, zo.pos(nb, p, u, i), v, s3);
             else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
         };
-        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out, tt);
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
 }
 
 // (the instantiations that carry all four forms of the spectrum -- !FAST: fp16 copy, fp32 dispersion -- need a few registers more than the
 //  80 of six waves per SIMD and spilled 24-28 bytes per lane under that cap: they ask for five, 96 registers, no scratch)
-// Twiddle-power tables of the single-transform z pass (fft_engine.h: TwiddleTables), behind the S+ table in LDS: the radix-8 stages with NS = 8
-// and NS = 64 at 2048 (504 entries, 4 KB: 30 KB per workgroup, five per CU -- the 1025 workgroups of a tile need 4.004), the NS = 8 stage alone
-// at 1024 (its other stages are radix 4) and at 4096 (a 4 KB table would cost the third workgroup per CU); none with a radix-16 plan.
-#ifndef OCEAN_C1_TWTAB
-#define OCEAN_C1_TWTAB 1
-#endif
-template <int N, class P> using C1TwiddleTables = TwiddleTables<N, P, (OCEAN_C1_TWTAB ? (N == 2048 ? 64 : 8) : 0)>;
-template <int N, class P> constexpr size_t zpass_c1_lds_bytes_for()
-{
-    return sizeof(c32) * fft_lds_elems<N, 1>() + sizeof(float) * N + sizeof(c32) * C1TwiddleTables<N, P>::total();
-}
+template <int N> constexpr size_t zpass_c1_lds_bytes() { return sizeof(c32) * fft_lds_elems<N, 1>() + sizeof(float) * N; }
 // (a radix-16 plan -- N / 16 threads, two waves per 2048-point workgroup -- may use the registers of three waves per SIMD: six workgroups per CU)
 template <int N, int T, bool FAST> constexpr int zpass_c1_min_waves() { return T == N / 16 ? 3 : (FAST ? 6 : 5); }
 template <int N, int T, class P, bool ZNT = false, bool Z16 = false, bool FAST = true, bool ZWT = false>
@@ -1413,9 +1115,7 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* fbuf = reinterpret_cast<c32*>(smem);                              // one transform
     float* sp = reinterpret_cast<float*>(fbuf + fft_lds_elems<N, 1>());    // S+ [N]
-    // until the first exchange the image holds, in the usual form (FAST), the phase table [0 .. wq_max] and in its last slot S-(0) of the column
-    constexpr bool PT = FAST && OCEAN_C1_PHASE_TABLE;
-    float* raw = reinterpret_cast<float*>(fbuf + (PT ? fft_lds_elems<N, 1>() - 1 : 0));
+    float* raw = reinterpret_cast<float*>(fbuf);                           // [0]: S-(0) of the column, until the first exchange
     const int tid = threadIdx.x;
     const int tile = blockIdx.y;
 #ifdef OCEAN_CLOCKPROBE
@@ -1424,11 +1124,6 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     start_ramp_wait(a.start_ramp, blockIdx.x, gridDim.x);         // (one 2048^2 tile: ocean_launch.h) -- ahead of every load: nothing is live across the wait
     TwiddleRegs<N, 1, T, P> twr;
     twr.load(a.tw, tid);
-    // the early stages' twiddle powers, once per workgroup for all four transforms (fft_engine.h: TwiddleTables); published by phase 1's barrier
-    using TT = C1TwiddleTables<N, P>;
-    c32* twtab = reinterpret_cast<c32*>(sp + N);
-    const TT tt{twtab};
-    static_assert(TT::total() == 0 || (FirstStage<N, 1, T, P>::IT == 1 && T >= 64), "a table row per thread, from its own base twiddles");
 #ifdef OCEAN_DEVELOPER      // (experiment: XCD x > 0 takes the column group of XCD 1 + (x - 1 + rot) % 7; group 0 holds one column more and stays)
     const int bxr = (blockIdx.x % 8 == 0 || a.xcd_rot == 0) ? (int)blockIdx.x : (int)(blockIdx.x / 8 * 8 + 1 + (blockIdx.x % 8 - 1 + a.xcd_rot) % 7);
     const int nb = xcd_swizzle(bxr, N / 2 + 1);
@@ -1453,31 +1148,13 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
             float2 hb0[PB], hb1[PB], wv[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u)
-                zpass_load_pair<N, H16, W16, ZNT, PT>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
-            if (ub == 0) TT::build(twtab, twr, tid);      // (behind the loads' issue: its inputs are twiddle registers fetched ahead of them)
-            if constexpr (PT) {
-                if (ub == 0) {          // the phase table, while the loads travel (see animate_with_phase)
-                    for (unsigned q = (unsigned)tid; q <= a.wq_max; q += (unsigned)T) {
-                        const float wt = mul_nocontract(mul_nocontract((float)q, base), t);
-                        float sn, cs;
-                        sincos_f32(wt, sn, cs);
-                        fbuf[q] = make_float2(sn, cs);
-                    }
-                    __syncthreads();
-                }
-            }
+                zpass_load_pair<N, H16, W16, ZNT>(a, tile, nb, 2 * (tid + (ub + u) * T), h16s, base, ha[u], hb0[u], hb1[u], wv[u]);
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int n = 2 * (tid + (ub + u) * T);
                 float a0, b0, a1, b1;
-                if constexpr (PT) {
-                    const unsigned two = __float_as_uint(wv[u].x);
-                    animate_with_phase(make_float2(ha[u].x, ha[u].y), hb0[u], fbuf[two & 0xffffu], a0, b0);
-                    animate_with_phase(make_float2(ha[u].z, ha[u].w), hb1[u], fbuf[two >> 16], a1, b1);
-                } else {
-                    animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
-                    animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
-                }
+                animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
+                animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
                 *reinterpret_cast<float2*>(sp + n) = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
                 if (n == 0) raw[0] = 0.5f * (a0 - b0);          // S-(0), for everybody (the FFT image is not in use yet)
             }
@@ -1495,8 +1172,8 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
     __syncthreads();
     const float sm0 = raw[0];
     static_assert(!ZWT || (!ZNT && !Z16), "write-through is a policy of the plain fp32 intermediates");
-    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb, tt);
-    else zpass_single_transforms<N, T, P, false, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb, tt);
+    if (col0) zpass_single_transforms<N, T, P, true, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
+    else zpass_single_transforms<N, T, P, false, ZNT, Z16, ZWT>(a, fbuf, sp, kzr, twr, k1[nb], sm0, tid, tile, nb);
 #ifdef OCEAN_CLOCKPROBE
     clock_probe_.end();
 #endif
@@ -2125,160 +1802,6 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
     if (a.rec_mode == 2) frame_done<T>(a, reinterpret_cast<unsigned*>(smem), tid);
 }
 
-#ifdef OCEAN_INIT_KERNELS
-// Device-to-host copy of a map by a kernel that stores into the page-locked destination through its device address (ocean_compute_waves_read,
-// small maps): 16 bytes per lane, grid-stride.  Two maps of 4 MiB land in 160 us this way against 176-184 us through the runtime's DMA engines
-// (which win from 16 MiB per map up: 56.3 against 54.3 GB/s at 64 MiB; tools/ubench/d2h.hip, profiles/r06_dropin_call.txt).
-__global__ void k_copy_out(const float4* __restrict__ src, float4* __restrict__ dst, size_t texels)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
-// Packed-map gather at half the bytes (the gather is xGMI-bound): one RGBA32F texel -> four halves
-// (round to nearest even; |values| of both maps are far below the largest half, 65504, for any sea the reference
-// parameters can describe -- larger values saturate to +-inf like any float -> half conversion).
-__global__ void k_pack_half(const float4* __restrict__ src, uint2* __restrict__ dst, size_t texels)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 v = src[i];
-        const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
-        uint2 o;
-        __builtin_memcpy(&o.x, &a, 4); __builtin_memcpy(&o.y, &b, 4);
-        dst[i] = o;
-    }
-}
-
-// ============================================================================
-// Vertex-stage consumer: what the reference's vertex shader does with
-// the two maps (src/shaders/WaterSurfaceMesh.vert:24-41) for the grid its mesh generator
-// builds (WaterSurfaceMesh.cpp:500-533), as a kernel -- displaced positions and normals for a
-// consumer that is not the Vulkan renderer.  Sampling is the sampler the reference creates
-// (vulkan/Sampler.cpp:60-66): LINEAR filter, REPEAT addressing, unnormalised coordinate
-// s = u*W - 0.5, texels floor(s) and floor(s)+1 (mod W), weights from frac(s), evaluated in
-// fp32 in the order written below (no contraction), which oracle/consumer.py repeats.
-// One thread per vertex; memory-bound (8 texel reads that mostly hit in cache, 2 writes).
-// ============================================================================
-struct GridArgs {
-    const float4* disp;      // [N][N] of the tile
-    const float4* nrm;
-    const unsigned* minmax;  // keys of the tile's raw height range (A = max(|min|, |max|) = WSHeightAmp)
-    float4* positions;       // [(g+1)^2]  xyz = displaced position, w = displacement.w (jacobian slot)
-    float4* normals;         // [(g+1)^2]  xyz = unit normal, w = 0
-    int n;                   // map size
-    int grid;                // quads per side (kTileSize of CreateGridVertices)
-    float vertex_distance;   // kScale
-    float uv_scale;          // ubo.scale
-    float choppy;            // ubo.WSChoppy = GetDisplacementLambda()
-};
-
-__device__ __forceinline__ float4 sample_linear_repeat(const float4* __restrict__ tex, int n, float u, float v)
-{
-#pragma clang fp contract(off)
-    const float s = u * (float)n - 0.5f, t = v * (float)n - 0.5f;
-    const float fs = floorf(s), ft = floorf(t);
-    const float a = s - fs, b = t - ft;
-    const int x0 = (int)fs & (n - 1), y0 = (int)ft & (n - 1);
-    const int x1 = (x0 + 1) & (n - 1), y1 = (y0 + 1) & (n - 1);
-    const float4 t00 = tex[(unsigned)(y0 * n + x0)], t10 = tex[(unsigned)(y0 * n + x1)];
-    const float4 t01 = tex[(unsigned)(y1 * n + x0)], t11 = tex[(unsigned)(y1 * n + x1)];
-    const float ia = 1.0f - a, ib = 1.0f - b;
-    auto mix = [&](float c00, float c10, float c01, float c11) {
-        return (c00 * ia + c10 * a) * ib + (c01 * ia + c11 * a) * b;
-    };
-    return make_float4(mix(t00.x, t10.x, t01.x, t11.x), mix(t00.y, t10.y, t01.y, t11.y),
-                       mix(t00.z, t10.z, t01.z, t11.z), mix(t00.w, t10.w, t01.w, t11.w));
-}
-
-__global__ void k_displace_grid(const GridArgs g)
-{
-#pragma clang fp contract(off)
-    const int side = g.grid + 1;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= side * side) return;
-    const int half = g.grid / 2;
-    const int xi = i % side - half, yi = i / side - half;          // WaterSurfaceMesh.cpp:514-518
-    const float px = (float)xi * g.vertex_distance, pz = (float)yi * g.vertex_distance;
-    const float u = (float)(xi + half) / (float)g.grid, v = (float)(yi + half) / (float)g.grid;
-    const float amp = fmaxf(fabsf(key_float(g.minmax[0])), fabsf(key_float(g.minmax[1])));
-    const float us = u * g.uv_scale, vs = v * g.uv_scale;          // .vert:26
-    float4 d = sample_linear_repeat(g.disp, g.n, us, vs);
-    d.y = d.y * amp;                                               // .vert:27
-    g.positions[i] = make_float4(px + d.x, 0.0f + d.y, pz + d.z, d.w);   // .vert:28-29
-    const float4 sl = sample_linear_repeat(g.nrm, g.n, us, vs);    // .vert:33
-    const float nx = -(sl.x / (1.0f + g.choppy * sl.z));           // .vert:34-38
-    const float nz = -(sl.y / (1.0f + g.choppy * sl.w));
-    const float len = sqrtf(nx * nx + 1.0f + nz * nz);
-    g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
-}
-
-// Cascades (the reference's own to-do "Endless - solving the tiling artifacts", README.md:37-44): the
-// usual cure for the visible repetition of one FFT tile is to add several tiles of different lengths and seeds, each
-// sampled at its own rate.  The tiles of a batch already are independent oceans with their own tile length, so the
-// consumer only has to sum them: vertex = grid point + sum_c D_c(uv * s_c) (each height times its own amplitude A_c),
-// normal from the summed slopes and summed displacement derivatives with the reference's formula (.vert:34-38).
-// w carries the smallest Jacobian slot of the cascades (all 1 unless OCEAN_MODE_JACOBIAN).
-constexpr int OCEAN_MAX_CASCADES = 8;
-struct CascadeArgs {
-    GridArgs g;                        // disp / nrm / minmax of the FIRST tile of the cascade; n, grid, vertex_distance, choppy
-    int count;
-    size_t tile_texels;                // N * N
-    float uv_scale[OCEAN_MAX_CASCADES];
-};
-
-__global__ void k_displace_grid_cascades(const CascadeArgs a)
-{
-#pragma clang fp contract(off)
-    const GridArgs& g = a.g;
-    const int side = g.grid + 1;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= side * side) return;
-    const int half = g.grid / 2;
-    const int xi = i % side - half, yi = i / side - half;
-    const float px = (float)xi * g.vertex_distance, pz = (float)yi * g.vertex_distance;
-    const float u = (float)(xi + half) / (float)g.grid, v = (float)(yi + half) / (float)g.grid;
-    float dx = 0.0f, dy = 0.0f, dz = 0.0f, w = 3.402823466e+38f;
-    float sx = 0.0f, sz = 0.0f, ddx = 0.0f, ddz = 0.0f;
-    for (int c = 0; c < a.count; ++c) {
-        const float us = u * a.uv_scale[c], vs = v * a.uv_scale[c];
-        const float amp = fmaxf(fabsf(key_float(g.minmax[2 * c + 0])), fabsf(key_float(g.minmax[2 * c + 1])));
-        const float4 d = sample_linear_repeat(g.disp + (size_t)c * a.tile_texels, g.n, us, vs);
-        const float4 sl = sample_linear_repeat(g.nrm + (size_t)c * a.tile_texels, g.n, us, vs);
-        dx = dx + d.x; dy = dy + d.y * amp; dz = dz + d.z;
-        w = fminf(w, d.w);
-        sx = sx + sl.x; sz = sz + sl.y; ddx = ddx + sl.z; ddz = ddz + sl.w;
-    }
-    g.positions[i] = make_float4(px + dx, 0.0f + dy, pz + dz, w);
-    const float nx = -(sx / (1.0f + g.choppy * ddx));
-    const float nz = -(sz / (1.0f + g.choppy * ddz));
-    const float len = sqrtf(nx * nx + 1.0f + nz * nz);
-    g.normals[i] = make_float4(nx / len, 1.0f / len, nz / len, 0.0f);
-}
-
-// Mip chain of the maps (the reference's LOD hook: s_kUseMipMapping, WaterSurfaceMesh.h:216; Texture2D::GenerateMipmaps,
-// vulkan/Texture2D.cpp:228-330 -- level i = vkCmdBlitImage(VK_FILTER_LINEAR) of level i-1 into half the extent).  An exact 2:1
-// linear blit samples the point shared by four source texels: the bilinear formula of sample_linear_repeat with both weights
-// 1/2, evaluated in the same order (oracle/consumer.py::mip_chain repeats it).  One launch per level, both maps per launch
-// (blockIdx.y); a level is N^2/4^l texels, so everything after the first two is launch latency.
-struct MipArgs {
-    const float4* src[2];    // level l-1 of the displacement map, of the normal map
-    float4* dst[2];          // level l
-    int w;                   // extent of level l (source extent 2w)
-};
-__global__ void k_mip_level(const MipArgs m)
-{
-#pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m.w * m.w) return;
-    const int x = i % m.w, y = i / m.w, sw = 2 * m.w;
-    const float4* __restrict__ s = m.src[blockIdx.y];
-    const float4 t00 = s[(unsigned)((2 * y) * sw + 2 * x)], t10 = s[(unsigned)((2 * y) * sw + 2 * x + 1)];
-    const float4 t01 = s[(unsigned)((2 * y + 1) * sw + 2 * x)], t11 = s[(unsigned)((2 * y + 1) * sw + 2 * x + 1)];
-    auto mix = [](float c00, float c10, float c01, float c11) { return (c00 * 0.5f + c10 * 0.5f) * 0.5f + (c01 * 0.5f + c11 * 0.5f) * 0.5f; };
-    m.dst[blockIdx.y][i] = make_float4(mix(t00.x, t10.x, t01.x, t11.x), mix(t00.y, t10.y, t01.y, t11.y),
-                                       mix(t00.z, t10.z, t01.z, t11.z), mix(t00.w, t10.w, t01.w, t11.w));
-}
-
-#endif  // OCEAN_INIT_KERNELS
 
 // ---- per-size launch geometry ---------------------------------------------------
 template <int N> struct Geo;
@@ -2319,6 +1842,5 @@ OCEAN_GEO(4096, 1024, OCEAN_R(8, 8, 8, 8), 2, 512, Plan<4096>)
 template <int N> constexpr bool zpass_c1_r16() { return N >= OCEAN_C1_R16_MIN && N >= 2048; }
 template <int N> constexpr int zpass_c1_threads() { return zpass_c1_r16<N>() ? N / 16 : N / 8; }
 template <int N> struct C1Plan { using type = std::conditional_t<zpass_c1_r16<N>(), Plan<N>, typename Geo<N>::PR>; };
-template <int N> constexpr size_t zpass_c1_lds_bytes() { return zpass_c1_lds_bytes_for<N, typename C1Plan<N>::type>(); }
 
 }  // namespace ocean

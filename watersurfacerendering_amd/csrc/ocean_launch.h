@@ -44,10 +44,7 @@ static hipError_t launch_frame(ocean_ctx* c, const FrameArgs& a, int stream_maps
     constexpr size_t lds_b = lds_m + sizeof(float) * 2 * ((G::T_C + 63) / 64);
     static_assert(HF::NUP % (2 * C) == 0, "height row blocks");
     constexpr unsigned hb_b = xpass_height_groups<N, C>(), nb = (HF::NU + C - 1) / C;
-    // the usual form of the spectrum: fp32 h0, 16-bit dispersion -- and, where the tile size has the single-transform z pass, few enough distinct
-    // multiples for its phase table (ocean_kernels.h: zpass_phase_table_capacity; 301 entries at 2048^2 with the reference's defaults against
-    // 2303); otherwise the instantiations that carry every form of the spectrum run (per-element sincos)
-    const bool fast = !a.h0h && a.omega_q && (!zpass_has_c1<N>() || a.wq_max < zpass_phase_table_capacity<N>());
+    const bool fast = !a.h0h && a.omega_q;       // the usual form of the spectrum: fp32 h0, 16-bit dispersion
     const bool alone = (stream_maps & 16) != 0;
     const unsigned cus = (unsigned)(c->cu_count > 0 ? c->cu_count : 0);
     // Staggered start (ocean_kernels.h: start_ramp_wait; the rule and its constants: OceanTuning, ocean_ctx.h).  A launch gets one when its WHOLE
