@@ -170,12 +170,12 @@ int ocean_get_heights(ocean_t* ctx, uint32_t tile, float* amp, float* min_h, flo
 int ocean_read_maps(ocean_t* ctx, uint32_t first_tile, uint32_t num_tiles, float* disp, float* nrm);
 /* ComputeWaves(t) AND the read-out of every tile's maps in one blocking call -- the reference's call shape, one ComputeWaves followed by two
  * memcpy's of the finished maps (WaterSurfaceMesh.cpp:145-154, 701-755): out_amp[tiles] (may be NULL), disp / nrm = tiles*N*N*4 floats each
- * (neither NULL).  Same results as ocean_compute_waves + ocean_read_maps(0, tiles), sooner: the normal map is final when the frame's second
- * launch ends, so its device-to-host copy runs on a copy stream beside the displacement pass, and the displacement map's copy follows behind
- * its kernel on the frame's stream -- one PCIe link kept busy from the second launch on; the call returns from a poll of the two copies'
- * events, not from a stream synchronisation.  Maps up to 8 MiB each go out by a copy kernel that stores through the destination's device
- * address (2 x 4 MiB: 160 us against 176-184 us through the DMA engines), larger ones through the runtime's DMA engines (56 GB/s at 64 MiB).
- * Register the destinations with ocean_host_register for that (pageable memory still works: staged, blocking copies).                      */
+ * (neither NULL).  Same results as ocean_compute_waves + ocean_read_maps(0, tiles), sooner.  With page-locked destinations
+ * (ocean_host_register) and maps up to 8 MiB each -- 512 x 512, the reference's default -- the two x-axis passes store every texel to the
+ * host arrays themselves, through their device addresses, beside the device copy: the maps cross PCIe while they are being produced and no
+ * copy follows the frame.  Larger maps go through the runtime's DMA engines (56 GB/s at 64 MiB per map against 54 for kernel stores): the
+ * normal map, final behind the frame's second launch, on a copy stream beside the displacement pass, the displacement map behind its kernel.
+ * The call returns from a poll of events, not from a stream synchronisation.  Pageable destinations still work (staged, blocking copies).   */
 int ocean_compute_waves_read(ocean_t* ctx, float t, float* out_amp, float* disp, float* nrm);
 
 /* Asynchronous read-out (the upload path after ComputeWaves,

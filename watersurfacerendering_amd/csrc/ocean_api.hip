@@ -602,6 +602,7 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     a.t = t;
     a.mode = c->mode;
     a.start_ramp = 0;       // (set per launch by the launcher where a staggered start pays: ocean_launch.h)
+    a.disp_host = c->host_out[0]; a.nrm_host = c->host_out[1];      // (ocean_compute_waves_read, small maps; null otherwise)
     a.zmask = 15; a.xb_roles = 3;                   // (per launch: the launcher's frame order)
     a.xcd_rot = 0;
 #ifdef OCEAN_DEVELOPER
@@ -830,50 +831,50 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->nrm_final) HIP_TRY(hipEventCreateWithFlags(&c->nrm_final, hipEventDisableTiming));
     for (auto& ev : c->copy_done) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->after_b = c->nrm_final; c->after_b_recorded = false;
+    const size_t bytes = (size_t)c->tiles * c->n * c->n * sizeof(float4);
+    // Small maps into page-locked memory: the x passes store them there themselves, beside the device copy (OceanTuning::host_store_max_bytes;
+    // ranges registered through ocean_host_register are found in the library's own list, others through the runtime).
+    void* dev_dst[2] = {nullptr, nullptr};
+    if (bytes <= c->tune.host_store_max_bytes) {
+        dev_dst[0] = pinned_device_address(disp, bytes);
+        dev_dst[1] = pinned_device_address(nrm, bytes);
+    }
+    const bool direct = dev_dst[0] && dev_dst[1];
+    c->host_out[0] = direct ? static_cast<float4*>(dev_dst[0]) : nullptr;
+    c->host_out[1] = direct ? static_cast<float4*>(dev_dst[1]) : nullptr;
+    c->after_b = direct ? nullptr : c->nrm_final; c->after_b_recorded = false;
     int rc = enqueue_frame(c, t, true, nullptr, true);
-    c->after_b = nullptr;
+    c->after_b = nullptr; c->host_out[0] = c->host_out[1] = nullptr;
     if (rc) return rc;
     const int set = c->last_set;
     hipStream_t st = stream_of(c, set);
-    const size_t bytes = (size_t)c->tiles * c->n * c->n * sizeof(float4);
     const float4* d = c->ext_disp ? c->ext_disp : c->dispN[set];
     const float4* q = c->ext_nrm ? c->ext_nrm : c->nrmN[set];
     hipStream_t nst = st;
-    if (c->after_b_recorded) {      // (frames whose x axis is one launch -- small tiles -- have no such point: both copies follow the frame)
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->nrm_final, 0));
-        nst = c->copy_stream;
+    if (!direct) {
+        if (c->after_b_recorded) {      // (frames whose x axis is one launch -- small tiles -- have no such point: both copies follow the frame)
+            HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->nrm_final, 0));
+            nst = c->copy_stream;
+        }
+        HIP_TRY(hipMemcpyAsync(nrm, q, bytes, hipMemcpyDeviceToHost, nst));
+        HIP_TRY(hipEventRecord(c->copy_done[0], nst));
+        HIP_TRY(hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st));
     }
-    // small maps into page-locked memory: a copy kernel (OceanTuning::copy_kernel_max_bytes); otherwise the runtime's copy
-    bool by_kernel = bytes <= c->tune.copy_kernel_max_bytes;
-    void* dev_dst[2] = {nullptr, nullptr};        // (per call: ranges registered through ocean_host_register from the library's own list, others from the runtime)
-    if (by_kernel) {
-        dev_dst[0] = pinned_device_address(nrm, bytes);
-        dev_dst[1] = pinned_device_address(disp, bytes);
-        by_kernel = dev_dst[0] && dev_dst[1];
-    }
-    const size_t texels = bytes / sizeof(float4);
-    const unsigned blocks = (unsigned)((texels + 255) / 256 < 1024 ? (texels + 255) / 256 : 1024);
-    if (by_kernel) hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, nst, q, static_cast<float4*>(dev_dst[0]), texels);
-    else HIP_TRY(hipMemcpyAsync(nrm, q, bytes, hipMemcpyDeviceToHost, nst));
-    HIP_TRY(hipEventRecord(c->copy_done[0], nst));
-    if (by_kernel) hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, st, d, static_cast<float4*>(dev_dst[1]), texels);
-    else HIP_TRY(hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st));
+    // (direct stores: the event behind the frame's last kernel says that its stores -- the host's included -- have been released)
     HIP_TRY(hipEventRecord(c->copy_done[1], st));
-    HIP_TRY(hipGetLastError());
-    rc = wait_frame(c, set);        // the frame's completion records (a poll): A, min, max -- the copies are still in flight
+    rc = wait_frame(c, set);        // the frame's completion records (a poll): A, min, max -- the maps may still be on their way
     if (rc == OCEAN_OK && c->fault_recoveries_seen != c->fault_recoveries) {
-        // the frame was run again (an in-launch wait had given up): what the copies took may be the wrong frame's -- copy again, plainly
+        // the frame was run again (an in-launch wait had given up): what reached the host may be the wrong frame's -- copy again, plainly
         c->fault_recoveries_seen = c->fault_recoveries;
         HIP_TRY(hipStreamSynchronize(nst)); HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(nrm, q, bytes, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(disp, d, bytes, hipMemcpyDeviceToHost));
     }
-    // the copies: polled like the records -- a blocking synchronisation's wake-up costs 13-16 us per call, and this call is the caller's
-    // whole frame (the reference's ComputeWaves keeps every core busy for its 44 ms) -- for up to 50 ms, then waited for
+    // the copies / the frame's release: polled like the records -- a blocking synchronisation's wake-up costs 13-16 us per call, and this call
+    // is the caller's whole frame (the reference's ComputeWaves keeps every core busy for its 44 ms) -- for up to 50 ms, then waited for
     using clock = std::chrono::steady_clock;
     const clock::time_point t0 = clock::now();
-    for (int k = 0; k < 2; ++k) {
+    for (int k = direct ? 1 : 0; k < 2; ++k) {
         unsigned spins = 0;
         for (;;) {
             const hipError_t e = hipEventQuery(c->copy_done[k]);

@@ -169,14 +169,6 @@ __global__ void k_inter_bounds(const float2* __restrict__ h0, const float* __res
 }
 
 
-// Device-to-host copy of a map by a kernel that stores into the page-locked destination through its device address (ocean_compute_waves_read,
-// small maps): 16 bytes per lane, grid-stride.  Two maps of 4 MiB land in 160 us this way against 176-184 us through the runtime's DMA engines
-// (which win from 16 MiB per map up: 56.3 against 54.3 GB/s at 64 MiB; tools/ubench/d2h.hip, profiles/r06_dropin_call.txt).
-__global__ void k_copy_out(const float4* __restrict__ src, float4* __restrict__ dst, size_t texels)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
 // Packed-map gather at half the bytes (the gather is xGMI-bound): one RGBA32F texel -> four halves
 // (round to nearest even; |values| of both maps are far below the largest half, 65504, for any sea the reference
 // parameters can describe -- larger values saturate to +-inf like any float -> half conversion).

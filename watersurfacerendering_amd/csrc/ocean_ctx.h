@@ -48,10 +48,11 @@ struct OceanTuning {
     // itself, and a rule that trusted the occupancy query alone lost 12 % on serial 5 x 1024^2 frames (z pass 33 -> 39-43 us; 3 and 4 tiles:
     // -1 ... +1 %; round 6, profiles/r06_tuning_rules.txt).  The launches that gain hold 1-5 per unit.
     unsigned ramp_max_wg_per_cu = 6;
-    // ocean_compute_waves_read: maps up to this size go to the host by a copy kernel (stores through the destination's device address), larger
-    // ones through the runtime's DMA engines: 2 x 4 MiB 160 us against 176-184, 2 x 16 MiB 625 against 617, 2 x 64 MiB 2470 against 2384 us
-    // (tools/ubench/d2h.hip, round 6).
-    size_t copy_kernel_max_bytes = (size_t)8 << 20;
+    // ocean_compute_waves_read: maps up to this size are stored to the page-locked destination by the x passes themselves (through its device
+    // address, beside the device copy), larger ones go through the runtime's DMA engines behind their kernels.  Stores from kernels cross PCIe
+    // at 52.5 GB/s, the DMA engines reach 45.5-47.9 at 2 x 4 MiB, 53.7-54.4 at 2 x 16 MiB and 56.3 at 2 x 64 MiB (kernel stores: 53.6, 54.3):
+    // tools/ubench/d2h.hip, round 6.
+    size_t host_store_max_bytes = (size_t)8 << 20;
     // Merged x pass / one-launch frame (in-launch hand-offs): only where every workgroup of the grid has a compute unit to itself
     // (MI355X_MICROARCH.md, inter-workgroup visibility: the regime the recipe is measured for).
     unsigned handoff_wg_per_cu = 1;
@@ -180,6 +181,8 @@ struct ocean_ctx {
     bool after_b_recorded = false;
     hipStream_t copy_stream = nullptr;  // ocean_compute_waves_read: the normal map's device-to-host copy runs here, beside the displacement pass
     hipEvent_t nrm_final = nullptr, copy_done[2] = {};   // its events: normal map final / the two copies have landed
+    float4* host_out[2] = {};           // set around its enqueue: device addresses of the caller's page-locked (displacement, normal) arrays when the
+                                        //   x passes are to store the maps there themselves (FrameArgs::disp_host / nrm_host), null otherwise
     int burst_pos = 0;                  // pipelined frames enqueued since the context's streams were last drained
     int z_last_set = -1;
     hipEvent_t consumer_ev = nullptr;   // behind the most recent consumer launch (mips, grid): the context-wide output buffers of

@@ -89,6 +89,14 @@ template <bool NTS> __device__ __forceinline__ void store_map(float4* base, unsi
 #endif
 }
 #define OCEAN_STORE(base, texel, val) store_map<NTS>((base), (unsigned)(texel), (val))
+// The same texel to a SECOND destination as well: the caller's page-locked host array, through its device address (ocean_compute_waves_read,
+// small maps: FrameArgs::disp_host / nrm_host; null -- a wave-uniform branch -- in every other frame).  The x passes then write the maps
+// across PCIe as they produce them, 1 KiB per wave instruction like the device copy, instead of a copy behind the frame: a blocking 512^2
+// call 191 -> 17x us (profiles/r06_dropin_call.txt).  The device copy stays complete: every other read-out sees the frame as before.
+__device__ __forceinline__ void store_map_host(float4* host_base, unsigned texel, float4 v)
+{
+    if (host_base) *reinterpret_cast<float4*>(reinterpret_cast<char*>(host_base) + (texel * 16u)) = v;
+}
 
 // Element `idx` of a per-tile array through a 32-bit BYTE offset (every per-tile array here is far
 // below 4 GiB): the access then addresses as scalar base + 32-bit vector offset instead of a 64-bit
@@ -221,6 +229,8 @@ struct FrameArgs {
                              // workgroups as well (7 = the merged x pass: the whole x axis in one launch, no k_xpass_disp)
     int xcd_rot;             // developer builds only (OCEAN_XCD_ROT, tools/xcd_rot.py): the single-transform z pass hands the column groups of XCDs 1..7 round
                              // by this many places -- which XCD writes which part of the intermediates -- 0 in the shipped library
+    float4* disp_host;       // [tiles][N][N] or null: the caller's page-locked destinations of ocean_compute_waves_read (device addresses): the x passes
+    float4* nrm_host;        //                        store every map texel there as well (store_map_host)
     int rec_mode;            // completion records of this launch: 0 none, 1 block 0 writes them early (untracked frame: the stream tells when it
                              // has finished), 2 the last workgroup to finish writes them (frame_done; tracked frame) -- the frame's LAST launch
 };
@@ -1008,11 +1018,34 @@ struct ClockProbe {
 // workgroups per CU, the same number of waves, and each one's load burst and store tail travel under the other's transforms.  Same radix
 // plan, same inputs (zpass_input), same twiddles: bit-identical to the other forms (tests/test_variants_gpu.py).
 // ============================================================================
+// Round 6: at 2048 and 4096 the four transforms run as wave-local 512-point transforms + one cross-wave stage (fft_engine.h: WaveFFT) -- two
+// workgroup barriers per transform instead of six.  The S+ table is then stored by sub-sequence, element e at (e % W) * 512 + e / W, so that a
+// wave's first-stage reads are one contiguous run (zpass_sp_index), and a thread's kz registers are those of its sub-sequence's elements.
+// The results differ from the other z-pass forms' in the last bits (another factorisation of the same transform): within the 1e-5 of the
+// oracle like them (tests/test_variants_gpu.py compares every form with the oracle; the forms of ONE tile size no longer with each other).
+#ifndef OCEAN_C1_WAVEFFT      // developer A/B: 0 = the engine's 8.8.8.(N / 512) plan with workgroup-wide exchanges, as in rounds 4-5
+#define OCEAN_C1_WAVEFFT 1
+#endif
+template <int N, int T> constexpr bool zpass_c1_wavefft() { return OCEAN_C1_WAVEFFT && (N == 2048 || N == 4096) && T == N / 8; }
+template <int N, int T> __device__ __forceinline__ int zpass_sp_index(int e)
+{
+    if constexpr (zpass_c1_wavefft<N, T>()) return (e & (N / 512 - 1)) * 512 + e / (N / 512);
+    else return e;
+}
+
 template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false>
 __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float (&kzr)[P::r[0]],
                                                         TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb)
 {
     using HF = Half<N>;
+    constexpr bool WF = zpass_c1_wavefft<N, T>();
+    [[maybe_unused]] WaveFFT<WF ? N : 2048, WF ? T : 256> wf;
+    if constexpr (WF) wf.load(a.tw, tid);
+    // one transform: the engine's plan, or the wave-local form (same input and output functors)
+    auto transform = [&](auto& in, auto& out) {
+        if constexpr (WF) wf.run(fbuf, tid, [&](int e, int i) { return in(e, 0, 0, i); }, [&](int p, c32 v, int u, int m) { out(p, 0, v, u, m); });
+        else batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+    };
     // kz of the first stage's inputs: thread j reads elements j + i * (N / R0), i = 0 .. R0-1, in every one of the four batches -- the
     // same R0 wave-vector components each time, so they live in registers (kzr[i], fetched once per workgroup from the k table) instead
     // of an LDS table: 16 KB less LDS at 4096 -- three workgroups per CU instead of two -- and a quarter of the first stages' LDS reads.
@@ -1032,13 +1065,13 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
     // S+(e), Tx(e), Tz(e), Tc(e) (see k_zpass: the Nyquist column carries G(e) = h~(e, 0) and forms S+- on the fly)
     auto fetch = [&](int e, float& sv, float& tx, float& tz, float& tc) {
         if constexpr (COL0) {
-            const float g1 = sp[e], g2 = sp[(N - e) & (N - 1)];
+            const float g1 = sp[zpass_sp_index<N, T>(e)], g2 = sp[zpass_sp_index<N, T>((N - e) & (N - 1))];
             sv = 0.5f * (g1 + g2);
             tx = 0.5f * (g1 - g2);
             tz = (e == 0) ? tx : sv;
             tc = (e == 0) ? sv : tx;
         } else {
-            sv = sp[e];
+            sv = sp[zpass_sp_index<N, T>(e)];
             tx = sv;
             tz = (e == 0) ? sm0 : sv;
             tc = tz;
@@ -1052,7 +1085,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, zo.pos(nb, p, u, i), v, su); };
-            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+            transform(in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
             auto in = [&](int e, int, int, int i) -> c32 {
@@ -1060,7 +1093,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+            transform(in, out);
         }
     }
     if ((a.mode == 0 || a.mode == 3) && (a.zmask & 4)) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
@@ -1069,7 +1102,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
         };
         auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+        transform(in, out);
     }
 #ifdef OCEAN_HALF_HEIGHT_MIN
     if constexpr (zpass_half_height<N>()) {
@@ -1100,7 +1133,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             if (jac) store_z<ZNT, Z16, ZWT>(z3, zo.pos(nb, p, u, i), v, s3);
             else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
         };
-        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
+        transform(in, out);
     }
 }
 
@@ -1155,7 +1188,9 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
                 float a0, b0, a1, b1;
                 animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
                 animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
-                *reinterpret_cast<float2*>(sp + n) = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
+                const float2 spv = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
+                if constexpr (zpass_c1_wavefft<N, T>()) { sp[zpass_sp_index<N, T>(n)] = spv.x; sp[zpass_sp_index<N, T>(n + 1)] = spv.y; }      // by sub-sequence
+                else *reinterpret_cast<float2*>(sp + n) = spv;
                 if (n == 0) raw[0] = 0.5f * (a0 - b0);          // S-(0), for everybody (the FFT image is not in use yet)
             }
         }
@@ -1167,8 +1202,10 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
         a.hdone[tile] = 0u;                                   // (merged x pass: its DISP workgroups count the HEIGHT workgroups up from here)
     }
     float kzr[P::r[0]];                                   // kz of this thread's first-stage inputs (behind phase 1: the registers are free by now)
+    static_assert(!zpass_c1_wavefft<N, T>() || P::r[0] == 8, "eight first-stage legs per thread in both forms");
 #pragma unroll
-    for (int i = 0; i < P::r[0]; ++i) kzr[i] = k1[tid + i * (N / P::r[0])];
+    for (int i = 0; i < P::r[0]; ++i)       // engine plan: elements tid + i N / R0; wave-local form: (N / 512) (lane + 64 i) + wave
+        kzr[i] = k1[zpass_c1_wavefft<N, T>() ? (N / 512) * ((tid & 63) + 64 * i) + (tid >> 6) : tid + i * (N / P::r[0])];
     __syncthreads();
     const float sm0 = raw[0];
     static_assert(!ZWT || (!ZNT && !Z16), "write-through is a policy of the plain fp32 intermediates");
@@ -1542,6 +1579,7 @@ __device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* 
     const float2* __restrict__ z2 = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(z1) + HF::Z_GROUP * ESN);
     [[maybe_unused]] const float uk = Z16 ? a.zscale[2 * tile].w : 1.0f;
     float4* __restrict__ nrm = a.nrm + (size_t)tile * N * N;
+    float4* __restrict__ nrm_host = a.nrm_host ? a.nrm_host + (size_t)tile * N * N : nullptr;
     [[maybe_unused]] float* __restrict__ jac0 = JAC ? a.jac0 + (size_t)tile * HF::HRAW_TILE : nullptr;
     [[maybe_unused]] const float lambda = a.lambda ? a.lambda[tile] : a.lambda_all;
     c32 held[LS::IT][LS::RL];
@@ -1555,8 +1593,11 @@ __device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* 
         if constexpr (JAC)          // (1 + lambda s dxDx)(1 + lambda s dzDz) of .cpp:423-425, finished by the displacement pass
             at32(jac0, hraw_index(N, p, q)) = (1.0f + lambda * o.z) * (1.0f + lambda * o.w);
         OCEAN_STORE(nrm, q * N + p, o);
-        if (q != 0 && q != N / 2)                                    // mirror: slopes odd, derivatives even
+        store_map_host(nrm_host, (unsigned)(q * N + p), o);
+        if (q != 0 && q != N / 2) {                                  // mirror: slopes odd, derivatives even
             OCEAN_STORE(nrm, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, -o.y, o.z, o.w));
+            store_map_host(nrm_host, (unsigned)((N - q) * N + ((N - p) & (N - 1))), make_float4(-o.x, -o.y, o.z, o.w));
+        }
     };
     const c32 zero = make_float2(0.0f, 0.0f);
     if constexpr (xpass_single_row_group<N, C>()) {
@@ -1649,6 +1690,7 @@ __device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* 
             [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
             const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
             float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
+            float4* __restrict__ disp_host = a.disp_host ? a.disp_host + (size_t)tile * N * N : nullptr;
             c32 dheld[LSD::IT][LSD::RL];
             if (a.mode != 2) {
                 auto in = [&](int nf, int c, int, int) -> c32 { return load_pair_column<N, Z16>(z0, nf, u0 + c, -1.0f, uu); };
@@ -1674,8 +1716,11 @@ __device__ __forceinline__ void xpass_b_body(const FrameArgs& a, unsigned char* 
                 const c32 v = dheld[u][i];
                 const float4 o = make_float4(sg * lambda * v.x, hv * inv_a, sg * lambda * v.y, 1.0f);
                 store_map<NTS>(disp, (unsigned)(q * N + p), o);
-                if (q != 0 && q != N / 2)       // mirror: the displacements are odd, the height even
+                store_map_host(disp_host, (unsigned)(q * N + p), o);
+                if (q != 0 && q != N / 2) {     // mirror: the displacements are odd, the height even
                     store_map<NTS>(disp, (unsigned)((N - q) * N + ((N - p) & (N - 1))), make_float4(-o.x, o.y, -o.z, 1.0f));
+                    store_map_host(disp_host, (unsigned)((N - q) * N + ((N - p) & (N - 1))), make_float4(-o.x, o.y, -o.z, 1.0f));
+                }
             });
         }
     };
@@ -1742,6 +1787,7 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
     [[maybe_unused]] const float uu = Z16 ? a.zscale[2 * tile].z : 1.0f;
     const float* __restrict__ hraw = a.hraw + (size_t)tile * HF::HRAW_TILE;
     float4* __restrict__ disp = a.disp + (size_t)tile * N * N;
+    float4* __restrict__ disp_host = a.disp_host ? a.disp_host + (size_t)tile * N * N : nullptr;
     // CC = map rows of this workgroup's group (C, or 1 for the group of row N/2)
     auto rows = [&](auto cc_tag) {
         constexpr int CC = decltype(cc_tag)::value;
@@ -1785,8 +1831,11 @@ __global__ void __launch_bounds__(T, (T == 512 ? 4 : 1)) k_xpass_disp(const Fram
             }
             const float4 o = make_float4(s * lambda * v.x, hv[u][i] * inv_a, s * lambda * v.y, w);
             OCEAN_STORE(disp, q * N + p, o);
-            if (q != 0 && q != N / 2)       // mirror: the displacements are odd, height and Jacobian even
+            store_map_host(disp_host, (unsigned)(q * N + p), o);
+            if (q != 0 && q != N / 2) {     // mirror: the displacements are odd, height and Jacobian even
                 OCEAN_STORE(disp, (N - q) * N + ((N - p) & (N - 1)), make_float4(-o.x, o.y, -o.z, w));
+                store_map_host(disp_host, (unsigned)((N - q) * N + ((N - p) & (N - 1))), make_float4(-o.x, o.y, -o.z, w));
+            }
         };
         if (a.mode == 2)                 // HEIGHT1: no horizontal displacement, no transform
             for_each_output<LS, T>(tid, [&](int p, int c, int u, int i) { out(p, c, make_float2(0.0f, 0.0f), u, i); });
