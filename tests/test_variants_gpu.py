@@ -204,17 +204,11 @@ def test_every_selectable_variant_meets_the_oracle(n, oracles):
             for li in (z, xb, xd):
                 assert bool(li["flags"] & A.OCEAN_LAUNCH_STAGGERED_START) == (n == 2048 and tiles == 1 and (li is not z or bool(z["flags"] & A.OCEAN_LAUNCH_SINGLE_TRANSFORM))), what
             seen.add((n, z["flags"] & ~(A.OCEAN_LAUNCH_SPLIT_LAST_ROUND | stag), z["per_workgroup"], xb["flags"] & ~(stag | merged), xd["flags"] & ~(stag | merged)))
-            # the store policies (and with them the forms of the z pass that share a radix plan) never change a bit.  Since round 6 the
-            # single-transform z pass of 2048 / 4096 factorises its transforms differently (wave-local 512-point transforms + one cross-wave
-            # stage: csrc/fft_engine.h, WaveFFT) from the two-column form that streamed 2048^2 intermediates use: those two agree with the
-            # oracle (above), not bit for bit with each other -- frames are compared within a form
-            form = bool(z["flags"] & A.OCEAN_LAUNCH_SINGLE_TRANSFORM) if n >= 2048 else None
+            # the store policies (and with them the one- and two-column z pass, the split last round) never change a bit
             if same is None:
-                same = {}
-            if form not in same:
-                same[form] = (d, q, h)
+                same = (d, q, h)
             else:
-                assert np.array_equal(same[form][0], d) and np.array_equal(same[form][1], q) and same[form][2] == h, what
+                assert np.array_equal(same[0], d) and np.array_equal(same[1], q) and same[2] == h, what
     want = expected_variants(n)
     assert seen == want, {"never launched": sorted(want - seen), "launched but not expected": sorted(seen - want)}
     assert not split_seen                   # (rounds 2-3 split the last round of a serial 2048^2 z pass; the single-transform form replaced it)

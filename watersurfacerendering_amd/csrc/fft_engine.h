@@ -476,91 +476,6 @@ __device__ __forceinline__ void batch_fft(c32* lds, TwiddleRegs<N, C, T, P, LM>&
     run_stages<N, C, T, P, 0, 1, LM>(lds, twr, tid, in, out);
 }
 
-// ---- length-N transform as N / 512 WAVE-LOCAL 512-point transforms + one radix-(N / 512) stage across the waves (round 6) -------------------------
-// A single-column batch of the engine above synchronises the whole workgroup twice per exchange: six barriers per 2048-point transform, and the
-// single-transform z pass -- whose time is its workgroups' dependent chains (profiles/r06_zpass_experiments.txt) -- runs four transforms per
-// column.  Decimation in time by W = N / 512:  X[k' + 512 m] = sum_r w_W^(r m) * ( w_N^(r k') * Y_r[k'] ),   Y_r = DFT_512 of x[W n + r],
-// lets wave r (64 lanes x 8 points) compute Y_r ALONE: its two exchanges go through its own 576-slot region of the image (the per-exchange
-// layouts of lds_index_x: both sides conflict-free) with no barrier at all -- LDS instructions of one wave execute in order -- and only the
-// last, radix-W stage crosses waves: every wave leaves its twisted Z_r in its own region, ONE barrier, and thread t reads Z_0..W-1[k] for its
-// k = t (+ T).  A second barrier protects a wave's region from its next transform's first write while the other waves still read it: two
-// barriers per transform instead of six.  Outputs arrive exactly as the radix-W last stage of the engine's plan hands them out (k + 512 m,
-// lane-contiguous k), so the store functors are the same.  The arithmetic differs from the 8.8.8.W plan's in the last bits (another
-// factorisation): parity is against the oracle.
-template <int N, int T> struct WaveFFT {
-    static constexpr int W = N / 512;                      // waves = sub-transforms = radix of the last stage
-    static_assert(T == 64 * W && (W == 4 || W == 8), "one wave per 512-point sub-transform");
-    static constexpr int PITCH = 576;                      // a wave's region (float2): 512 + the padding of the per-exchange layouts
-    static constexpr int IT = 512 / T == 0 ? 1 : 512 / T;  // last-stage butterflies per thread
-    c32 w1, w2;                                            // base twiddles of the sub-transform's stages 1 (NS = 8) and 2 (NS = 64)
-    c32 tb, ts;                                            // twist w_N^(r lane) and its step w_N^(64 r)
-    int r, lane;
-    __device__ __forceinline__ void load(const c32* __restrict__ tw, int tid)      // tw[k] = exp(+2 pi i k / N)
-    {
-        r = tid >> 6; lane = tid & 63;
-        w1 = tw[(N / 64) * (lane & 7)];                    // exp(2 pi i (j % 8) / 64)
-        w2 = tw[(N / 512) * lane];                         // exp(2 pi i (j % 64) / 512)
-        tb = tw[r * lane];
-        ts = tw[64 * r];
-    }
-    // element of the sub-sequence handled by this thread's leg i of the first stage: e = W * (lane + 64 i) + r
-    __device__ __forceinline__ int element(int i) const { return W * (lane + 64 * i) + r; }
-    // in(e, i): input element e (leg i of this thread's first butterfly); out(p, value, u, m): output position p = k + 512 m of item u
-    template <class In, class Out>
-    __device__ __forceinline__ void run(c32* image, int tid, In&& in, Out&& out)
-    {
-        typedef __attribute__((address_space(3))) volatile v2 lds_v2;
-        lds_v2* L = (lds_v2*)image + r * PITCH;
-        // launder the twiddles (see batch_fft: keeps the power chains from being hoisted across consecutive transforms)
-        asm volatile("" : "+v"(w1.x), "+v"(w1.y), "+v"(w2.x), "+v"(w2.y), "+v"(tb.x), "+v"(tb.y));
-        v2 x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = tov(in(element(i), i));
-        Dft<8>::run(x);
-        __syncthreads();                                   // the other waves have read this wave's Z_r of the previous transform
-        {   // exchange 1, layout idx + idx / 16: this lane's outputs 8 lane + i
-            const int wb = 8 * lane + (lane >> 1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) L[wb + i] = x[i];
-            const int rb = lane + (lane >> 4);             // elements lane + 64 i -> + 68 i
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = L[rb + 68 * i];
-        }
-        apply_twiddles<8>(x, tov(w1));
-        Dft<8>::run(x);
-        {   // exchange 2, layout idx + 8 (idx / 64): outputs 64 (lane / 8) + lane % 8 + 8 i
-            const int wb = 72 * (lane >> 3) + (lane & 7);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) L[wb + 8 * i] = x[i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = L[lane + 72 * i];      // elements lane + 64 i
-        }
-        apply_twiddles<8>(x, tov(w2));
-        Dft<8>::run(x);                                    // x[i] = Y_r[lane + 64 i]
-        if (r != 0) {                                      // twist: Z_r[k'] = w_N^(r k') Y_r[k'], k' = lane + 64 i (wave-uniform branch)
-            v2 t = tov(tb);
-            const v2 st = tov(ts);
-            x[0] = pk_cmul(x[0], t);
-#pragma unroll
-            for (int i = 1; i < 8; ++i) { t = pk_cmul(t, st); x[i] = pk_cmul(x[i], t); }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) L[lane + 64 * i] = x[i];          // Z_r, natural order, in this wave's own region
-        __syncthreads();
-        lds_v2* A = (lds_v2*)image;
-#pragma unroll
-        for (int u = 0; u < IT; ++u) {
-            const int k = tid + u * T;
-            v2 z[W];
-#pragma unroll
-            for (int q = 0; q < W; ++q) z[q] = A[q * PITCH + k];
-            Dft<W>::run(z);
-#pragma unroll
-            for (int m = 0; m < W; ++m) out(k + 512 * m, toc(z[m]), u, m);
-        }
-    }
-};
-
 // Mapping of the FIRST stage: work item w = tid + u*T reads inputs
 // idx = j + i*(N/R0), column c, with j = w / C, c = w % C  (in(idx, c, u, i)).
 template <int N, int C, int T, class P = Plan<N>> struct FirstStage {

@@ -1018,34 +1018,11 @@ struct ClockProbe {
 // workgroups per CU, the same number of waves, and each one's load burst and store tail travel under the other's transforms.  Same radix
 // plan, same inputs (zpass_input), same twiddles: bit-identical to the other forms (tests/test_variants_gpu.py).
 // ============================================================================
-// Round 6: at 2048 and 4096 the four transforms run as wave-local 512-point transforms + one cross-wave stage (fft_engine.h: WaveFFT) -- two
-// workgroup barriers per transform instead of six.  The S+ table is then stored by sub-sequence, element e at (e % W) * 512 + e / W, so that a
-// wave's first-stage reads are one contiguous run (zpass_sp_index), and a thread's kz registers are those of its sub-sequence's elements.
-// The results differ from the other z-pass forms' in the last bits (another factorisation of the same transform): within the 1e-5 of the
-// oracle like them (tests/test_variants_gpu.py compares every form with the oracle; the forms of ONE tile size no longer with each other).
-#ifndef OCEAN_C1_WAVEFFT      // developer A/B: 0 = the engine's 8.8.8.(N / 512) plan with workgroup-wide exchanges, as in rounds 4-5
-#define OCEAN_C1_WAVEFFT 1
-#endif
-template <int N, int T> constexpr bool zpass_c1_wavefft() { return OCEAN_C1_WAVEFFT && (N == 2048 || N == 4096) && T == N / 8; }
-template <int N, int T> __device__ __forceinline__ int zpass_sp_index(int e)
-{
-    if constexpr (zpass_c1_wavefft<N, T>()) return (e & (N / 512 - 1)) * 512 + e / (N / 512);
-    else return e;
-}
-
 template <int N, int T, class P, bool COL0, bool ZNT, bool Z16, bool ZWT = false>
 __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32* fbuf, const float* sp, const float (&kzr)[P::r[0]],
                                                         TwiddleRegs<N, 1, T, P>& twr, float kx, float sm0, int tid, int tile, int nb)
 {
     using HF = Half<N>;
-    constexpr bool WF = zpass_c1_wavefft<N, T>();
-    [[maybe_unused]] WaveFFT<WF ? N : 2048, WF ? T : 256> wf;
-    if constexpr (WF) wf.load(a.tw, tid);
-    // one transform: the engine's plan, or the wave-local form (same input and output functors)
-    auto transform = [&](auto& in, auto& out) {
-        if constexpr (WF) wf.run(fbuf, tid, [&](int e, int i) { return in(e, 0, 0, i); }, [&](int p, c32 v, int u, int m) { out(p, 0, v, u, m); });
-        else batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
-    };
     // kz of the first stage's inputs: thread j reads elements j + i * (N / R0), i = 0 .. R0-1, in every one of the four batches -- the
     // same R0 wave-vector components each time, so they live in registers (kzr[i], fetched once per workgroup from the k table) instead
     // of an LDS table: 16 KB less LDS at 4096 -- three workgroups per CU instead of two -- and a quarter of the first stages' LDS reads.
@@ -1065,13 +1042,13 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
     // S+(e), Tx(e), Tz(e), Tc(e) (see k_zpass: the Nyquist column carries G(e) = h~(e, 0) and forms S+- on the fly)
     auto fetch = [&](int e, float& sv, float& tx, float& tz, float& tc) {
         if constexpr (COL0) {
-            const float g1 = sp[zpass_sp_index<N, T>(e)], g2 = sp[zpass_sp_index<N, T>((N - e) & (N - 1))];
+            const float g1 = sp[e], g2 = sp[(N - e) & (N - 1)];
             sv = 0.5f * (g1 + g2);
             tx = 0.5f * (g1 - g2);
             tz = (e == 0) ? tx : sv;
             tc = (e == 0) ? sv : tx;
         } else {
-            sv = sp[zpass_sp_index<N, T>(e)];
+            sv = sp[e];
             tx = sv;
             tz = (e == 0) ? sm0 : sv;
             tc = tz;
@@ -1085,7 +1062,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<0>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, zo.pos(nb, p, u, i), v, su); };
-            transform(in, out);
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
         if (a.zmask & 2) {   // pair 1: (-kz Tz, kx Tx)
             auto in = [&](int e, int, int, int i) -> c32 {
@@ -1093,7 +1070,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
                 return zpass_input<1>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
             };
             auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-            transform(in, out);
+            batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
         }
     }
     if ((a.mode == 0 || a.mode == 3) && (a.zmask & 4)) {   // pair 2: (kx ux S+, kz uz S+) -- only the 7-field modes read it
@@ -1102,7 +1079,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             return zpass_input<2>(kx, kx2, kzr[i], sv, tx, tz, tc, 1.0f, false, 1.0f);
         };
         auto out = [&](int p, int, c32 v, int u, int i) { store_z<ZNT, Z16, ZWT>(zt, 2u * (unsigned)HF::Z_GROUP + zo.pos(nb, p, u, i), v, sk); };
-        transform(in, out);
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
 #ifdef OCEAN_HALF_HEIGHT_MIN
     if constexpr (zpass_half_height<N>()) {
@@ -1133,7 +1110,7 @@ __device__ __forceinline__ void zpass_single_transforms(const FrameArgs& a, c32*
             if (jac) store_z<ZNT, Z16, ZWT>(z3, zo.pos(nb, p, u, i), v, s3);
             else if (zo.keeps(p, i)) store_z<ZNT, Z16, ZWT>(zh, zo.hpos(nb, p, u, i), v, su);     // real input: other half is the conjugate
         };
-        transform(in, out);
+        batch_fft<N, 1, T, P>(fbuf, twr, tid, in, out);
     }
 }
 
@@ -1188,9 +1165,7 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
                 float a0, b0, a1, b1;
                 animate_with_mirror(make_float2(ha[u].x, ha[u].y), hb0[u], wv[u].x, t, a0, b0);
                 animate_with_mirror(make_float2(ha[u].z, ha[u].w), hb1[u], wv[u].y, t, a1, b1);
-                const float2 spv = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
-                if constexpr (zpass_c1_wavefft<N, T>()) { sp[zpass_sp_index<N, T>(n)] = spv.x; sp[zpass_sp_index<N, T>(n + 1)] = spv.y; }      // by sub-sequence
-                else *reinterpret_cast<float2*>(sp + n) = spv;
+                *reinterpret_cast<float2*>(sp + n) = col0 ? make_float2(a0, a1) : make_float2(0.5f * (a0 + b0), 0.5f * (a1 + b1));
                 if (n == 0) raw[0] = 0.5f * (a0 - b0);          // S-(0), for everybody (the FFT image is not in use yet)
             }
         }
@@ -1202,10 +1177,8 @@ __global__ void __launch_bounds__(T, (zpass_c1_min_waves<N, T, FAST>())) k_zpass
         a.hdone[tile] = 0u;                                   // (merged x pass: its DISP workgroups count the HEIGHT workgroups up from here)
     }
     float kzr[P::r[0]];                                   // kz of this thread's first-stage inputs (behind phase 1: the registers are free by now)
-    static_assert(!zpass_c1_wavefft<N, T>() || P::r[0] == 8, "eight first-stage legs per thread in both forms");
 #pragma unroll
-    for (int i = 0; i < P::r[0]; ++i)       // engine plan: elements tid + i N / R0; wave-local form: (N / 512) (lane + 64 i) + wave
-        kzr[i] = k1[zpass_c1_wavefft<N, T>() ? (N / 512) * ((tid & 63) + 64 * i) + (tid >> 6) : tid + i * (N / P::r[0])];
+    for (int i = 0; i < P::r[0]; ++i) kzr[i] = k1[tid + i * (N / P::r[0])];
     __syncthreads();
     const float sm0 = raw[0];
     static_assert(!ZWT || (!ZNT && !Z16), "write-through is a policy of the plain fp32 intermediates");
