@@ -263,17 +263,17 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_committed_bench_line_is_reproducible_from_profiles(bench):
-    """The committed default bench run (profiles/r05n_bench_default.json = the compact stdout line, profiles/r05n_bench_extra_default.json = its
-    sidecar) against the committed rocprofv3 summary (profiles/kernel_stats.json <- r05n_kernel_stats_2048_bench_depth1.csv) and the byte
+    """The committed default bench run (profiles/r06n_bench_default.json = the compact stdout line, profiles/r06n_bench_extra_default.json = its
+    sidecar) against the committed rocprofv3 summary (profiles/kernel_stats.json <- r06n_kernel_stats_2048_bench_depth1.csv) and the byte
     accounting of this file: every kernel's fraction within 8 % of the one recomputed from the rocprofv3 average (two processes on two boxes: the
     hardware queue a context's stream lands on moves a kernel by up to +-1 us, profiles/r03_bimodal_probe.txt section 4a), nothing above 1, the
     line below the size limit, and the summaries regenerate from the CSV."""
     prof = os.path.join(ROOT, "profiles")
-    raw = open(os.path.join(prof, "r05n_bench_default.json")).read()
+    raw = open(os.path.join(prof, "r06n_bench_default.json")).read()
     lines = [l for l in raw.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < bench.LINE_BYTES_MAX
     d = json.loads(lines[0])
-    side = json.load(open(os.path.join(prof, "r05n_bench_extra_default.json")))
+    side = json.load(open(os.path.join(prof, "r06n_bench_extra_default.json")))
     assert side["line"] == d
     st = json.load(open(os.path.join(prof, "kernel_stats.json")))
     r = d["roofline"]
@@ -303,7 +303,7 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     import csv
     import re
     acc = {}
-    for row in csv.DictReader(open(os.path.join(prof, "r05n_kernel_stats_2048_bench_depth1.csv"))):
+    for row in csv.DictReader(open(os.path.join(prof, "r06n_kernel_stats_2048_bench_depth1.csv"))):
         m = re.search(r"(k_[a-z_0-9]+)<2048", row["Name"])
         name = m.group(1) if m else None
         if name and name.startswith("k_zpass"):          # the z pass's kernel forms (k_zpass, k_zpass_c1) are all the frame's first launch
