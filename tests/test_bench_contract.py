@@ -297,7 +297,7 @@ def test_committed_bench_line_is_reproducible_from_profiles(bench):
     sc = ex["2048x2048_synchronous_calls"]
     assert sc["calls"] >= 1000 and sc["pinned_thread_gc_off"]["p95_over_median"] <= 1.15
     # the driver's invocation, committed beside it: parsed line, the same keys
-    short = json.loads([l for l in open(os.path.join(prof, "r05n_bench_steps20_warmup5.json")).read().splitlines() if l.startswith("{")][-1])
+    short = json.loads([l for l in open(os.path.join(prof, "r06n_bench_steps20_warmup5.json")).read().splitlines() if l.startswith("{")][-1])
     assert short["steps"] == 20 and short["warmup"] == 5 and set(short) == set(d) and short["roofline"]["frac"] < 1.0
     # the summary itself regenerates from the committed CSV
     import csv
