@@ -850,8 +850,9 @@ def main():
                 bs.compute_waves_async(DT * j)
             bs.synchronize()
         ms_i, kern_i = bs.time_frames(0.0, DT, 100, nk, per_kernel=True)
+        placed = bs.placement_report()
         bs.close()
-        serial_passes.append((ms_i / nk * 1e3, kern_i, when, kern_cold))
+        serial_passes.append((ms_i / nk * 1e3, kern_i, when, kern_cold, placed))
     for j in range(min(args.prewarm, 200)):            # (the first frames of the process: module load, first touch)
         b.compute_waves_async(DT * j)
     sync()
@@ -927,6 +928,9 @@ def main():
                                          "roofline.launch_us reports); per pass, in the order of serial_passes_us",
                                  "clock_ramping": [p[3][0] * 1e3 for p in serial_passes], "sustained_clock": [p[1][0] * 1e3 for p in serial_passes]}
         r["serial_passes_us"] = [{"when": p[2], "frame": p[0], **{k: v * 1e3 for k, v in zip(names, p[1])}} for p in serial_passes]
+        r["placement_search"] = {"what": "ocean_prepare's placement search in each serial pass's context (include/ocean_dev.h): candidate allocations of spectrum + "
+                                         "intermediates timed, serial frame us of the one kept and of the slowest -- the spread is what a context without the "
+                                         "search could have drawn", "per_pass": [{"candidates": p[4][0], "us_chosen": p[4][1], "us_slowest": p[4][2]} for p in serial_passes]}
         if kern_ms_main is not None:
             r["serial_kernels_in_bench_context_us"] = {k: v * 1e3 for k, v in zip(names, kern_ms_main)}
         return r

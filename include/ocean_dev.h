@@ -39,6 +39,16 @@ int ocean_set_start_ramp(ocean_t* ctx, int on);
  * as ONE launch (OCEAN_LAUNCH_ONE_LAUNCH; 64^2: 11.5 -> 3.9 us per frame at depth 4).                                                                                                          */
 int ocean_set_merged_xpass(ocean_t* ctx, int on);
 
+/* Placement search of ocean_prepare (round 6).  The speed of the frame's first pass depends on where the spectrum and the intermediates happen to
+ * be allocated -- contexts created back to back in one process run the SAME 2048 x 2048 z pass in 19.8 ... 28.6 us, each stable for the
+ * context's life (profiles/r06_slow_window.txt) -- so ocean_prepare, like the reference's Prepare with its FFTW_MEASURE plans
+ * (WSTessendorf.cpp:191-232), measures: from 1024 x 1024 up it allocates a few candidate copies of that buffer group, times serial frames on
+ * each and keeps the fastest (6 candidates, ~45 ms at 2048 x 2048; frames are bit-identical wherever the buffers are).  trials = 0: the
+ * library's rule; 1: off; n: that many candidates at any size.  Takes effect at the next ocean_prepare.  ocean_placement_report: what the most
+ * recent ocean_prepare did -- candidates timed (0: none) and the serial frame time of the chosen and of the slowest candidate (us).         */
+int ocean_set_placement_search(ocean_t* ctx, int trials);
+int ocean_placement_report(const ocean_t* ctx, int* trials, float* us_chosen, float* us_worst);
+
 /* ---- introspection for tests and the bench -------------------------------- */
 /* Copies the Prepare() products of one tile to host: h0 (N*N*2), omega (N*N).   */
 int ocean_read_spectrum(ocean_t* ctx, uint32_t tile, float* h0, float* omega);

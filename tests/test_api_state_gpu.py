@@ -571,3 +571,49 @@ def test_compute_waves_read_is_compute_waves_plus_read_maps(n, tiles, depth):
     assert L.ocean_compute_waves_read(b._h, 0.0, None, None, q.ctypes.data) == A.OCEAN_E_INVALID
     assert b.fault_recoveries == 0
     b.close()
+
+
+def test_placement_search_changes_no_bit_and_reports():
+    """ocean_prepare's placement search (round 6; include/ocean_dev.h): from 1024^2 up Prepare times a few candidate allocations of the spectrum +
+    intermediates on serial frames and keeps the fastest -- the same 2048^2 z pass runs 19.8 ... 28.6 us depending on where those buffers landed
+    (profiles/r06_slow_window.txt).  Frames do not depend on it bit for bit; the report says what was done; below 1024^2 nothing is searched
+    unless asked for; the calibration frames leave nothing to read out; re-Prepare searches again."""
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi as A
+    for n, tiles in ((1024, 1), (2048, 1), (1024, 3)):
+        frames = []
+        for trials in (1, 0, 9):
+            b = W.OceanBatch(n, tiles, 0)
+            b.set_placement_search(trials)
+            b.prepare(SEED + 31)
+            tried, chosen, worst = b.placement_report()
+            if trials == 1:
+                assert (tried, chosen, worst) == (0, 0.0, 0.0)
+            else:
+                assert tried == (6 if trials == 0 else 9) and 0.0 < chosen <= worst < 10.0 * chosen, (n, tiles, trials, tried, chosen, worst)
+            with pytest.raises(W.OceanError) as e:            # the maps hold a calibration frame: nothing to read out before the first frame
+                b.read_maps()
+            assert e.value.code == A.OCEAN_E_NOT_READY
+            a = b.compute_waves(1.75)
+            d, q = b.read_maps()
+            h0, om = b.read_spectrum(tiles - 1)
+            b.set_pipeline_depth(2)
+            for j in range(4):
+                b.compute_waves_async(0.1 * j)
+            b.compute_waves_async(1.75); b.synchronize()
+            d2, q2 = b.read_maps()
+            assert np.array_equal(d, d2) and np.array_equal(q, q2)
+            frames.append((a, d, q, h0, om))
+            if trials == 9:                                     # a second Prepare searches again and delivers the same ocean
+                b.prepare(SEED + 31)
+                assert b.placement_report()[0] == 9
+                a3 = b.compute_waves(1.75); d3, q3 = b.read_maps()
+                assert np.array_equal(a3, a) and np.array_equal(d3, d) and np.array_equal(q3, q)
+            b.close()
+        for other in frames[1:]:
+            assert all(np.array_equal(x, y) for x, y in zip(frames[0], other)), (n, tiles)
+    b = W.OceanBatch(512, 1, 0); b.prepare(SEED)
+    assert b.placement_report()[0] == 0                          # the reference's default size: Prepare stays as cheap as it was
+    b.set_placement_search(3); b.prepare(SEED)
+    assert b.placement_report()[0] == 3
+    b.close()

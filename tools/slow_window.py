@@ -83,17 +83,32 @@ T0 = time.time()
 frame = [0]          # frames this context has run = the chain's sequence number of the last one
 
 
-def window(label, nframes=4000):
+def addresses(ctx, label):
+    """developer builds: device addresses of the context's buffers (ocean_debug_buffers) -- alignment against 2 MiB / 1 GiB"""
+    try:
+        fn = L.ocean_debug_buffers
+    except AttributeError:
+        return
+    fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    out = (C.c_void_p * 8)()
+    if fn(ctx._h, 0, out) == 0:
+        names = ("h0", "omega_q", "z", "zh", "hraw", "minmax", "disp", "nrm")
+        print(f"   buffers of {label}: " + "  ".join(f"{n} {int(v or 0):#x} (mod 2 MiB {int(v or 0) % (2 << 20):#x})" for n, v in zip(names, out)))
+
+
+def window(label, nframes=4000, ctx=None, counter=None):
     """nframes serial frames (depth 1, one stream: each z pass has the device to itself between its x passes), then the probe records."""
+    ctx = b if ctx is None else ctx
+    counter = frame if counter is None else counter
     t0 = time.time()
-    first = frame[0] + 1
+    first = counter[0] + 1
     for j in range(nframes):
-        b.compute_waves_async(0.05 * j)
-    b.synchronize()
+        ctx.compute_waves_async(0.05 * j)
+    ctx.synchronize()
     t1 = time.time()
-    frame[0] += nframes
+    counter[0] += nframes
     buf = np.zeros((LAUNCHES, WGS, 4), dtype=np.uint64)
-    W._abi.check(probe(b._h, 0, buf.ctypes.data_as(C.c_void_p), 0, buf.size), "ocean_debug_clockprobe")
+    W._abi.check(probe(ctx._h, 0, buf.ctypes.data_as(C.c_void_p), 0, buf.size), "ocean_debug_clockprobe")
     seqs = np.arange(first, first + nframes)
     rec = buf[seqs % LAUNCHES][:, :NWG, :]
     start, end, cyc, ids = (rec[..., k] for k in range(4))
@@ -139,10 +154,27 @@ def window(label, nframes=4000):
     return med, float(np.median(clk))
 
 
+addresses(b, "ctx0")
 window("fresh0 (first serial frames of the process)")
+addresses(b, "ctx0")
 window("fresh1")
 window("fresh2")
 if SOAK_S <= 0:          # quick mode (A/B of kernel variants by cycles per launch): three windows, no soak
+    if os.environ.get("OCEAN_REALLOC_TEST"):        # is the slow state a property of a context's ALLOCATION?  More contexts, the earlier ones kept alive
+        keep = []
+        for k in range(int(os.environ["OCEAN_REALLOC_TEST"])):
+            if k % 2 == 1:                          # (every other one behind a 96 MiB allocation that shifts what the next context gets)
+                import torch
+                keep.append(torch.empty(96 << 20, dtype=torch.uint8, device="cuda"))
+            c2 = W.OceanBatch(2048, 1, 0); c2.prepare(0x5EED0000)
+            W._abi.check(probe(c2._h, 1, None, 0, 0), "ocean_debug_clockprobe")
+            c2.compute_waves(0.0)
+            cnt = [1]
+            addresses(c2, f"ctx{k + 1}")
+            window(f"ctx{k + 1} (another context, the earlier ones alive) warm-up", 1000, c2, cnt)
+            window(f"ctx{k + 1} (another context, the earlier ones alive)", 3000, c2, cnt)
+            keep.append(c2)
+        window("ctx0 again (the first context)", 3000)
     if os.environ.get("OCEAN_XCD_ROT_SWEEP"):       # developer build: which XCD writes which column group, rotated window by window
         for rot in (1, 2, 3, 4, 5, 6, 0, 3, 0):
             os.environ["OCEAN_XCD_ROT"] = str(rot)

@@ -113,6 +113,16 @@ class OceanBatch:
                                                     q.ctypes.data_as(C.c_void_p)), "ocean_compute_waves_read")
         return amp, d, q
 
+    def set_placement_search(self, trials: int):
+        """Candidates the next prepare() times for the spectrum + intermediates (ocean_set_placement_search): 0 = the library's rule, 1 = off."""
+        _abi.check(self._L.ocean_set_placement_search(self._h, int(trials)), "ocean_set_placement_search")
+
+    def placement_report(self):
+        """(candidates timed by the most recent prepare(), serial frame us of the chosen one, of the slowest one)."""
+        n, a, b = C.c_int(), C.c_float(), C.c_float()
+        _abi.check(self._L.ocean_placement_report(self._h, C.byref(n), C.byref(a), C.byref(b)), "ocean_placement_report")
+        return n.value, a.value, b.value
+
     @property
     def fault_recoveries(self) -> int:
         """How often the host re-ran frames because an in-launch wait had given up (ocean_fault_recoveries; 0 on a dedicated device)."""

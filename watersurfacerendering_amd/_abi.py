@@ -44,7 +44,7 @@ SYMBOLS_CONSUMERS = [       # include/ocean_consumers.h: SURVEY.md 8f ranks 3-4
 ]
 SYMBOLS_DEV = [             # include/ocean_dev.h: tests, bench.py, tools/
     "ocean_read_spectrum", "ocean_read_xi",
-    "ocean_select_streams", "ocean_set_start_ramp", "ocean_set_merged_xpass", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
+    "ocean_select_streams", "ocean_set_start_ramp", "ocean_set_merged_xpass", "ocean_set_placement_search", "ocean_placement_report", "ocean_time_frames", "ocean_kernel_name", "ocean_last_launch", "ocean_algorithmic_bytes_per_texel", "ocean_algorithmic_bytes_per_launch",
 ]
 SYMBOLS = SYMBOLS_BOUNDARY + SYMBOLS_CONSUMERS + SYMBOLS_DEV
 HEADERS = {"ocean.h": SYMBOLS_BOUNDARY, "ocean_consumers.h": SYMBOLS_CONSUMERS, "ocean_dev.h": SYMBOLS_DEV}
@@ -164,6 +164,8 @@ def lib() -> C.CDLL:
         "ocean_build_id": (C.c_char_p, []),
         "ocean_last_hip_error": (i32, []),
         "ocean_fault_recoveries": (C.c_uint, [P]),
+        "ocean_set_placement_search": (i32, [P, i32]),
+        "ocean_placement_report": (i32, [P, C.POINTER(i32), FP, FP]),
         "ocean_compute_waves_read": (i32, [P, f32, FP, P, P]),
         "ocean_create": (i32, [C.POINTER(P), u32, u32, i32]),
         "ocean_destroy": (None, [P]),

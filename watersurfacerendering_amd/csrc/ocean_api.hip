@@ -185,6 +185,7 @@ static int alloc_device(ocean_ctx* c)
 // enqueued behind such a frame has consumed it (OCEAN_E_HIP / hipErrorLaunchTimeOut from this call; the context is usable, the consumer call is
 // the caller's to repeat).
 static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* marks, bool track, int redo_set);
+static int placement_search(ocean_ctx* c);
 static bool fault_raised(const ocean_ctx* c) { return c->fault && __atomic_load_n(c->fault, __ATOMIC_ACQUIRE) != 0u; }
 static void reset_pipeline_state(ocean_ctx* c)
 {
@@ -516,7 +517,7 @@ int ocean_prepare(ocean_t* c, uint64_t seed, const float* xi_or_null)
     c->prepared = true;
     c->have_frame = false;
     if (c->fault) *c->fault = 0u;
-    return OCEAN_OK;
+    return placement_search(c);
 }
 
 }  // extern "C"
@@ -680,7 +681,101 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
     return OCEAN_OK;
 }
 
+// ---- placement search (OceanTuning::placement_trials; include/ocean_dev.h: ocean_set_placement_search) ---------------------------------------
+// The buffer group the frame's first pass reads and writes -- spectrum, dispersion (both forms), the intermediates of chain 0 -- is allocated
+// `trials` times, all candidates alive at once (freed memory would come straight back), filled alike, and serial frames are timed on each in
+// turn behind a common warm-up (the shader clock needs ~25 ms of load after an idle gap); the context keeps the fastest group and frees the
+// rest.  Frames do not depend on where their buffers are: same bits.  Skipped where calibration frames must not run (caller-owned stream or
+// output) or the group is not the usual one (fp16 copy of the spectrum).
+static int placement_search(ocean_ctx* c)
+{
+    c->placement_tried = 0; c->placement_us_chosen = c->placement_us_worst = 0.0f;
+    const size_t n = c->n, n2 = n * n, t = c->tiles;
+    const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
+    const size_t bytes[5] = {t * n2 * sizeof(float2), t * n2 * sizeof(float), t * n2 * sizeof(uint16_t), t * 3 * nu * 2 * nup * sizeof(float2), t * nu * nup * sizeof(float2)};
+    size_t group = 0;
+    for (size_t b : bytes) group += b;
+    int trials = c->placement_override > 0 ? c->placement_override
+                                           : ((c->n >= c->tune.placement_min_n && group <= c->tune.placement_max_group_bytes) ? c->tune.placement_trials : 1);
+    if (trials > 16) trials = 16;
+    if (trials <= 1 || c->user || c->ext_disp || c->ext_nrm || c->h0_bits == 16) return OCEAN_OK;
+    { int rc_ = alloc_set(c, 0); if (rc_) return rc_; }
+    hipStream_t st = stream_of(c, 0);
+    struct Group { void* p[5]; };
+    std::vector<Group> cand((size_t)trials);
+    cand[0] = Group{{c->h0, c->omega, c->omega_q, c->z[0], c->zh[0]}};
+    auto release = [&](Group& g) { for (void*& q : g.p) if (q) { (void)hipFree(q); q = nullptr; } };
+    for (int k = 1; k < trials; ++k) {
+        cand[(size_t)k] = Group{{nullptr, nullptr, nullptr, nullptr, nullptr}};
+        bool ok = true;
+        for (int b = 0; b < 5 && ok; ++b) ok = hipMalloc(&cand[(size_t)k].p[b], bytes[b]) == hipSuccess;
+        for (int b = 0; b < 3 && ok; ++b) ok = hipMemcpyAsync(cand[(size_t)k].p[b], cand[0].p[b], bytes[b], hipMemcpyDeviceToDevice, st) == hipSuccess;
+        for (int b = 3; b < 5 && ok; ++b) ok = hipMemsetAsync(cand[(size_t)k].p[b], 0, bytes[b], st) == hipSuccess;       // (padded columns must read as zero)
+        if (!ok) { (void)hipGetLastError(); release(cand[(size_t)k]); trials = k; break; }       // out of memory: search among what there is
+    }
+    if (trials <= 1) return OCEAN_OK;
+    auto use = [&](const Group& g) {
+        c->h0 = static_cast<float2*>(g.p[0]); c->omega = static_cast<float*>(g.p[1]); c->omega_q = static_cast<uint16_t*>(g.p[2]);
+        c->z[0] = static_cast<float2*>(g.p[3]); c->zh[0] = static_cast<float2*>(g.p[4]);
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = OCEAN_OK;
+    auto frames = [&](int count) { for (int j = 0; j < count && rc == OCEAN_OK; ++j) rc = enqueue_frame(c, 0.05f * (float)j, false, nullptr, false); };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = OCEAN_E_HIP;
+    // warm-up on the first candidate: 30 ms of frames (host clock), so that every candidate is timed at the sustained shader clock
+    const auto w0 = std::chrono::steady_clock::now();
+    while (rc == OCEAN_OK && std::chrono::steady_clock::now() - w0 < std::chrono::milliseconds(30)) {
+        frames(32);
+        if (rc == OCEAN_OK && hipStreamSynchronize(st) != hipSuccess) rc = OCEAN_E_HIP;
+    }
+    const int timed = c->n >= 4096 ? 16 : 40;
+    std::vector<float> us((size_t)trials, 0.0f);
+    for (int k = 0; k < trials && rc == OCEAN_OK; ++k) {
+        use(cand[(size_t)k]);
+        frames(8);
+        if (rc == OCEAN_OK && hipEventRecord(e0, st) != hipSuccess) rc = OCEAN_E_HIP;
+        frames(timed);
+        if (rc == OCEAN_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = OCEAN_E_HIP;
+        float ms = 0.0f;
+        if (rc == OCEAN_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = OCEAN_E_HIP;
+        us[(size_t)k] = ms * 1000.0f / (float)timed;
+    }
+    (void)hipStreamSynchronize(st);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    int best = 0;
+    if (rc == OCEAN_OK) {
+        for (int k = 1; k < trials; ++k) if (us[(size_t)k] < us[(size_t)best]) best = k;
+        c->placement_tried = trials;
+        c->placement_us_chosen = us[(size_t)best];
+        c->placement_us_worst = *std::max_element(us.begin(), us.end());
+    } else {
+        (void)hipGetLastError();
+    }
+    use(cand[(size_t)best]);
+    for (int k = 0; k < trials; ++k) if (k != best) release(cand[(size_t)k]);
+    c->have_frame = false;                      // (the maps hold a calibration frame: nothing to read out until the caller's first frame)
+    for (bool& v : c->frame_valid) v = false;
+    return rc;
+}
+
 extern "C" {
+
+int ocean_set_placement_search(ocean_t* c, int trials)
+{
+    if (!c || trials < 0) return OCEAN_E_INVALID;
+    c->placement_override = trials;
+    return OCEAN_OK;
+}
+
+int ocean_placement_report(const ocean_t* c, int* trials, float* us_chosen, float* us_worst)
+{
+    if (!c) return OCEAN_E_INVALID;
+    if (trials) *trials = c->placement_tried;
+    if (us_chosen) *us_chosen = c->placement_us_chosen;
+    if (us_worst) *us_worst = c->placement_us_worst;
+    return OCEAN_OK;
+}
 
 int ocean_compute_waves_async(ocean_t* c, float t)
 {

@@ -53,6 +53,15 @@ struct OceanTuning {
     // at 52.5 GB/s, the DMA engines reach 45.5-47.9 at 2 x 4 MiB, 53.7-54.4 at 2 x 16 MiB and 56.3 at 2 x 64 MiB (kernel stores: 53.6, 54.3):
     // tools/ubench/d2h.hip, round 6.
     size_t host_store_max_bytes = (size_t)8 << 20;
+    // Placement search at Prepare (round 6, profiles/r06_slow_window.txt item 7): how fast the z pass runs is a property of WHERE its spectrum
+    // and intermediates were allocated -- contexts created one after the other in one process, same code, same second: 19.8 / 21.6 / 23.1 /
+    // 26.7 / 28.6 us per 2048^2 z pass, each stable for the context's life.  Like the reference's own Prepare, which lets FFTW_MEASURE time
+    // candidate plans (WSTessendorf.cpp:191-232), ocean_prepare therefore times `placement_trials` candidate allocations of that buffer group
+    // (all held at once, so that they ARE different memory) on serial frames and keeps the fastest.  From this tile size up, while one group
+    // stays below the byte bound; ocean_set_placement_search(ctx, n) overrides (1 = off).
+    int placement_trials = 6;
+    unsigned placement_min_n = 1024;
+    size_t placement_max_group_bytes = (size_t)512 << 20;
     // Merged x pass / one-launch frame (in-launch hand-offs): only where every workgroup of the grid has a compute unit to itself
     // (MI355X_MICROARCH.md, inter-workgroup visibility: the regime the recipe is measured for).
     unsigned handoff_wg_per_cu = 1;
@@ -133,6 +142,9 @@ struct ocean_ctx {
     bool last_handoff[MAXD] = {};   // ... it used an in-launch hand-off (merged x pass / one-launch frame: the only forms whose waits can give up)
     bool handoff = false;           // set by launch_frame: the frame it has just enqueued uses an in-launch hand-off
     bool recovering = false;        // recover_fault is re-enqueueing (no recursion)
+    int placement_override = 0;     // ocean_set_placement_search: 0 = the library's rule (OceanTuning), n >= 1 = that many candidates (1 = off)
+    int placement_tried = 0;        // what the most recent ocean_prepare did: candidates timed (0: no search), and their serial frame times
+    float placement_us_chosen = 0.0f, placement_us_worst = 0.0f;
     unsigned fault_recoveries = 0;  // recoveries after an in-launch wait gave up (ocean_fault_recoveries)
     unsigned fault_recoveries_seen = 0;   // ... that ocean_compute_waves_read has accounted for
     float4* dispN[MAXD] = {};      // internal map sets (set 0 always; others on first use): ONE allocation per set,
