@@ -692,31 +692,41 @@ static int placement_search(ocean_ctx* c)
     c->placement_tried = 0; c->placement_us_chosen = c->placement_us_worst = 0.0f;
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
-    const size_t bytes[5] = {t * n2 * sizeof(float2), t * n2 * sizeof(float), t * n2 * sizeof(uint16_t), t * 3 * nu * 2 * nup * sizeof(float2), t * nu * nup * sizeof(float2)};
+    enum { NB = 7 };                                // spectrum, dispersion (two forms), chain 0's intermediates (three), chain 0's maps
+    const size_t bytes[NB] = {t * n2 * sizeof(float2), t * n2 * sizeof(float), t * n2 * sizeof(uint16_t), t * 3 * nu * 2 * nup * sizeof(float2),
+                              t * nu * nup * sizeof(float2), t * nup * n * sizeof(float), c->maps_bytes[0]};
+    // which of them differ between candidates (developer switch for attribution runs: tools/placement_probe.py)
+    unsigned mask = c->tune.placement_mask;
+    if (const char* e = std::getenv("OCEAN_PLACEMENT_MASK")) mask = (unsigned)std::strtoul(e, nullptr, 0);
+    const bool trace = std::getenv("OCEAN_PLACEMENT_TRACE") != nullptr;
+    mask &= (1u << NB) - 1;
     size_t group = 0;
-    for (size_t b : bytes) group += b;
+    for (int b = 0; b < NB; ++b) if (mask >> b & 1) group += bytes[b];
     int trials = c->placement_override > 0 ? c->placement_override
                                            : ((c->n >= c->tune.placement_min_n && group <= c->tune.placement_max_group_bytes) ? c->tune.placement_trials : 1);
     if (trials > 16) trials = 16;
-    if (trials <= 1 || c->user || c->ext_disp || c->ext_nrm || c->h0_bits == 16) return OCEAN_OK;
+    if (trials <= 1 || !mask || c->user || c->ext_disp || c->ext_nrm || c->h0_bits == 16) return OCEAN_OK;
     { int rc_ = alloc_set(c, 0); if (rc_) return rc_; }
     hipStream_t st = stream_of(c, 0);
-    struct Group { void* p[5]; };
+    struct Group { void* p[NB]; };
     std::vector<Group> cand((size_t)trials);
-    cand[0] = Group{{c->h0, c->omega, c->omega_q, c->z[0], c->zh[0]}};
-    auto release = [&](Group& g) { for (void*& q : g.p) if (q) { (void)hipFree(q); q = nullptr; } };
+    cand[0] = Group{{c->h0, c->omega, c->omega_q, c->z[0], c->zh[0], c->hraw[0], c->dispN[0]}};
+    auto varies = [&](int b) { return (mask >> b & 1) != 0; };
+    auto release = [&](Group& g) { for (int b = 0; b < NB; ++b) if (varies(b) && g.p[b]) { (void)hipFree(g.p[b]); g.p[b] = nullptr; } };
     for (int k = 1; k < trials; ++k) {
-        cand[(size_t)k] = Group{{nullptr, nullptr, nullptr, nullptr, nullptr}};
+        Group& g = cand[(size_t)k];
         bool ok = true;
-        for (int b = 0; b < 5 && ok; ++b) ok = hipMalloc(&cand[(size_t)k].p[b], bytes[b]) == hipSuccess;
-        for (int b = 0; b < 3 && ok; ++b) ok = hipMemcpyAsync(cand[(size_t)k].p[b], cand[0].p[b], bytes[b], hipMemcpyDeviceToDevice, st) == hipSuccess;
-        for (int b = 3; b < 5 && ok; ++b) ok = hipMemsetAsync(cand[(size_t)k].p[b], 0, bytes[b], st) == hipSuccess;       // (padded columns must read as zero)
-        if (!ok) { (void)hipGetLastError(); release(cand[(size_t)k]); trials = k; break; }       // out of memory: search among what there is
+        for (int b = 0; b < NB; ++b) g.p[b] = varies(b) ? nullptr : cand[0].p[b];
+        for (int b = 0; b < NB && ok; ++b) if (varies(b)) ok = hipMalloc(&g.p[b], bytes[b]) == hipSuccess;
+        for (int b = 0; b < 3 && ok; ++b) if (varies(b)) ok = hipMemcpyAsync(g.p[b], cand[0].p[b], bytes[b], hipMemcpyDeviceToDevice, st) == hipSuccess;
+        for (int b = 3; b < 6 && ok; ++b) if (varies(b)) ok = hipMemsetAsync(g.p[b], 0, bytes[b], st) == hipSuccess;       // (padded columns must read as zero)
+        if (!ok) { (void)hipGetLastError(); release(g); trials = k; break; }       // out of memory: search among what there is
     }
     if (trials <= 1) return OCEAN_OK;
     auto use = [&](const Group& g) {
         c->h0 = static_cast<float2*>(g.p[0]); c->omega = static_cast<float*>(g.p[1]); c->omega_q = static_cast<uint16_t*>(g.p[2]);
-        c->z[0] = static_cast<float2*>(g.p[3]); c->zh[0] = static_cast<float2*>(g.p[4]);
+        c->z[0] = static_cast<float2*>(g.p[3]); c->zh[0] = static_cast<float2*>(g.p[4]); c->hraw[0] = static_cast<float*>(g.p[5]);
+        c->dispN[0] = static_cast<float4*>(g.p[6]); c->nrmN[0] = c->dispN[0] + t * n2;
     };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = OCEAN_OK;
@@ -749,6 +759,11 @@ static int placement_search(ocean_ctx* c)
         c->placement_tried = trials;
         c->placement_us_chosen = us[(size_t)best];
         c->placement_us_worst = *std::max_element(us.begin(), us.end());
+        if (trace) {
+            std::fprintf(stderr, "ocean placement search (mask 0x%x):", mask);
+            for (int k = 0; k < trials; ++k) std::fprintf(stderr, " %.2f", (double)us[(size_t)k]);
+            std::fprintf(stderr, " us/frame\n");
+        }
     } else {
         (void)hipGetLastError();
     }

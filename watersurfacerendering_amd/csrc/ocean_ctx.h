@@ -62,6 +62,7 @@ struct OceanTuning {
     int placement_trials = 6;
     unsigned placement_min_n = 1024;
     size_t placement_max_group_bytes = (size_t)512 << 20;
+    unsigned placement_mask = 0x1f;               // which buffers differ between candidates: bit 0 spectrum, 1-2 dispersion, 3-5 chain 0's intermediates, 6 its maps
     // Merged x pass / one-launch frame (in-launch hand-offs): only where every workgroup of the grid has a compute unit to itself
     // (MI355X_MICROARCH.md, inter-workgroup visibility: the regime the recipe is measured for).
     unsigned handoff_wg_per_cu = 1;
