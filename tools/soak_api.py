@@ -1,5 +1,5 @@
 """Soak of the frame path's host side (round 3): thousands of randomly mixed operations -- synchronous calls (tracked: completion records),
-asynchronous frames with and without tracking, ocean_wait_frame, read-outs (plain, asynchronous into registered memory, staging layout), mode /
+asynchronous frames with and without tracking, ocean_wait_frame, ocean_compute_waves_read, read-outs (plain, asynchronous into registered memory, staging layout), mode /
 depth / lambda / parameter / dispersion / precision / time-offset changes, resizes, mip chains, the vertex-stage consumer, dma-buf exports -- on
 one long-lived context, every returned amplitude and (sampled) map checked against a second context that only ever runs fully synchronised
 serial frames and is re-created from scratch now and then (so that stale state in the long-lived one cannot hide in both).
@@ -38,9 +38,18 @@ def ref(t):
 for k in range(ops):
     op = rng.random()
     t = round(rng.uniform(0.0, 50.0), 3)
-    if op < 0.35:
+    if op < 0.29:
         got = b.compute_waves(t); last_t = t
         bad += not np.array_equal(got, ref(t)); checked += 1
+    elif op < 0.35:
+        # round 6: the one-call frame + read-out (direct host stores for small page-locked destinations, copies otherwise)
+        pinned = rng.random() < 0.5
+        d = np.empty((tiles, n, n, 4), np.float32); q = np.empty_like(d)
+        if pinned: W.host_register(d); W.host_register(q)
+        got, _, _ = b.compute_waves_read(t, d, q); last_t = t
+        if pinned: W.host_unregister(d); W.host_unregister(q)
+        want = ref(t); d2, q2 = r.read_maps()
+        bad += not (np.array_equal(got, want) and np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
     elif op < 0.60:
         b.compute_waves_async(t); last_t = t
         if rng.random() < 0.5:
@@ -50,8 +59,10 @@ for k in range(ops):
         d, q = b.read_maps(tiles - 1, 1)
         ref(last_t); d2, q2 = r.read_maps(tiles - 1, 1)
         bad += not (np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
-    elif op < 0.75:
+    elif op < 0.74:
         b.set_frame_tracking(rng.random() < 0.5)
+    elif op < 0.75:
+        b.set_merged_xpass(rng.random() < 0.7)       # (round 5/6: in-launch hand-offs on / off; same bits)
     elif op < 0.80:
         state["depth"] = rng.choice([1, 2, 3, 5]); b.set_pipeline_depth(state["depth"])
     elif op < 0.85:
@@ -61,7 +72,8 @@ for k in range(ops):
     elif op < 0.92:
         state["seed"] = rng.randrange(1 << 30); reprepare(); last_t = None
     elif op < 0.93:
-        n = rng.choice(sizes); b.set_tile_size(n); r.set_tile_size(n); reprepare(); last_t = None
+        n = rng.choice(sizes); b.set_tile_size(n); r.set_tile_size(n)
+        b.set_placement_search(rng.choice([0, 1, 3])); reprepare(); last_t = None      # (round 6: Prepare's placement search on / off / forced at any size)
     elif op < 0.94:
         what = rng.randrange(6)
         if what == 0: state["inter"] = rng.choice([16, 32])
