@@ -59,3 +59,24 @@ def isolated(fn):
             pytest.xfail(report)
         pytest.fail(report, pytrace=False)
     return wrapper
+
+
+_PINNED_POOL = {}
+
+
+def pinned_array(shape, dtype, fill=0, tag=""):
+    """A page-locked numpy array from a process-wide pool: registered ONCE through ocean_host_register and kept until the process ends -- the
+    adaptor's pattern (include/WSTessendorf.hpp registers its vectors once per size).  The GPU suite does not register and unregister host
+    ranges test by test: on this ROCm stack a process that churns registrations while it also copies into pageable memory now and then dies
+    of a page fault inside the runtime's on-the-fly pinning (profiles/r06_hostreg_churn_fault.txt; tools/soak_api.py reproduces it with
+    SOAK_SKIP=churn, 10-30 % of 6000-operation runs; with persistent registrations 0 of 32)."""
+    import numpy as np
+    import watersurfacerendering_amd as W
+    key = (tuple(shape) if hasattr(shape, "__len__") else (int(shape),), np.dtype(dtype).str, tag)
+    if key not in _PINNED_POOL:
+        a = np.empty(key[0], dtype=dtype)
+        W.host_register(a)
+        _PINNED_POOL[key] = a
+    a = _PINNED_POOL[key]
+    a[...] = fill
+    return a

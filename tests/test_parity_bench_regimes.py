@@ -16,6 +16,7 @@ Reference lines: WSTessendorf.cpp:284-455.
 import os
 
 import numpy as np
+from conftest import pinned_array
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -275,15 +276,11 @@ def test_native_rccl_gather_single_rank_and_staging_layout():
     # staging layout, odd mesh sizes so that the pad matters
     vb, ib = 1000 * 32 + 4, 2998 * 4
     off = (vb + ib + 15) // 16 * 16
-    staging = np.full(off + 2 * n * n * 16 + 64, 0xAB, dtype=np.uint8)
-    W.host_register(staging)
-    try:
-        b.set_pipeline_depth(1)
-        b.compute_waves_async(0.6)
-        flush = b.read_maps_staging(staging, vb, ib, tile=1)
-        b.synchronize()
-    finally:
-        W.host_unregister(staging)
+    staging = pinned_array(off + 2 * n * n * 16 + 64, np.uint8, fill=0xAB)
+    b.set_pipeline_depth(1)
+    b.compute_waves_async(0.6)
+    flush = b.read_maps_staging(staging, vb, ib, tile=1)
+    b.synchronize()
     d, q = b.read_maps(1, 1)
     assert flush == off + 2 * n * n * 16
     assert np.all(staging[:off] == 0xAB) and np.all(staging[flush:] == 0xAB)          # mesh data and the tail untouched
@@ -328,10 +325,9 @@ def test_readout_paths_under_pipelining_refer_to_the_last_frame():
     n = 256
     ref = make_batch(n, seed=321)
     b = make_batch(n, seed=321, depth=3)
-    pinned = np.zeros((2, n, n, 4), dtype=np.float32)
-    staging = np.zeros(48 + 2 * n * n * 16, dtype=np.uint8)
-    W.host_register(pinned); W.host_register(staging)
-    try:
+    pinned = pinned_array((2, n, n, 4), np.float32)
+    staging = pinned_array(48 + 2 * n * n * 16, np.uint8)
+    if True:
         for frames in (1, 2, 3, 4, 5):
             times = [0.11 * (frames * 10 + j) for j in range(frames)]
             for t in times:
@@ -351,8 +347,6 @@ def test_readout_paths_under_pipelining_refer_to_the_last_frame():
             assert np.array_equal(pos, rpos), frames
             pd, pq = b.device_maps()                                 # zero-copy pointers of that same frame's maps
             assert pd and pq and pd != pq
-    finally:
-        W.host_unregister(pinned); W.host_unregister(staging)
     ref.close(); b.close()
 
 

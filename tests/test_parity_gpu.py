@@ -7,6 +7,7 @@ against the oracle run with float64 FFTs; amplitude A, min, max: relative 1e-6
 of A.  The HIP path is fp32 throughout (observed error ~3e-7).
 """
 import numpy as np
+from conftest import pinned_array
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -505,17 +506,13 @@ def test_async_readout_into_registered_host_memory():
     import watersurfacerendering_amd as W
     n = 512
     b = W.OceanBatch(n, 1, 0); b.prepare(17)
-    staging = np.zeros((2, n, n, 4), dtype=np.float32)
-    W.host_register(staging)
-    try:
-        for t in (0.5, 1.0):
-            b.compute_waves_async(t)
-            b.read_maps_async(staging[0:1], staging[1:2])
-            b.synchronize()
-            d, q = b.read_maps()
-            assert np.array_equal(staging[0], d[0]) and np.array_equal(staging[1], q[0])
-    finally:
-        W.host_unregister(staging)
+    staging = pinned_array((2, n, n, 4), np.float32)
+    for t in (0.5, 1.0):
+        b.compute_waves_async(t)
+        b.read_maps_async(staging[0:1], staging[1:2])
+        b.synchronize()
+        d, q = b.read_maps()
+        assert np.array_equal(staging[0], d[0]) and np.array_equal(staging[1], q[0])
     b.close()
 
 

@@ -32,23 +32,50 @@ def fresh_reference():
     r.set_lambda(state["lam"]); r.set_time_offsets(state["offs"]); r.prepare(state["seed"])
 reprepare()
 last_t, checked, bad = None, 0, 0
+trace = bool(os.environ.get("SOAK_TRACE"))
+import ctypes as C
+_hip = C.CDLL("libamdhip64.so"); kept = []; pool = {}
+skip = set(os.environ.get("SOAK_SKIP", "").split(","))      # debugging: leave out "read", "merge", "search", "pin"
 def ref(t):
     r.compute_waves_async(t); r.synchronize()
     return np.array([r.heights(i)[0] for i in range(tiles)], dtype=np.float32)
 for k in range(ops):
     op = rng.random()
     t = round(rng.uniform(0.0, 50.0), 3)
+    if trace: print(f"op {k} {op:.4f} n={n} depth={state['depth']} mode={state['mode']}", file=sys.stderr, flush=True)
     if op < 0.29:
         got = b.compute_waves(t); last_t = t
         bad += not np.array_equal(got, ref(t)); checked += 1
-    elif op < 0.35:
+    elif op < 0.35 and "read" not in skip:
         # round 6: the one-call frame + read-out (direct host stores for small page-locked destinations, copies otherwise)
-        pinned = rng.random() < 0.5
-        d = np.empty((tiles, n, n, 4), np.float32); q = np.empty_like(d)
-        if pinned: W.host_register(d); W.host_register(q)
-        got, _, _ = b.compute_waves_read(t, d, q); last_t = t
-        if pinned: W.host_unregister(d); W.host_unregister(q)
-        want = ref(t); d2, q2 = r.read_maps()
+        pinned = rng.random() < 0.5 and "pin" not in skip
+        persistent = pinned and "churn" not in skip
+        if persistent:              # the adaptor's pattern (include/WSTessendorf.hpp): destinations registered once per size and kept
+            if n not in pool:
+                pool[n] = (np.empty((tiles, n, n, 4), np.float32), np.empty((tiles, n, n, 4), np.float32))
+                for a in pool[n]: W.host_register(a)
+            d, q = pool[n]
+        else:
+            d = np.empty((tiles, n, n, 4), np.float32); q = np.empty_like(d)
+        if trace: print(f"   read pinned={pinned} d={d.ctypes.data:#x} q={q.ctypes.data:#x} bytes={d.nbytes}", file=sys.stderr, flush=True)
+        if pinned and "rawreg" in skip:      # debugging: the runtime's calls directly, not ocean_host_register
+            for a in (d, q): assert _hip.hipHostRegister(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 0) == 0
+        elif pinned and not persistent: W.host_register(d); W.host_register(q)
+        if trace: print("   registered", file=sys.stderr, flush=True)
+        if "oldapi" in skip:      # debugging: the same registered destinations through round 5's calls
+            got = b.compute_waves(t); b.read_maps_async(d, q); b.synchronize(); last_t = t
+        else:
+            got, _, _ = b.compute_waves_read(t, d, q); last_t = t
+        if trace: print("   call returned", file=sys.stderr, flush=True)
+        if pinned and "rawreg" in skip:
+            for a in (d, q): assert _hip.hipHostUnregister(C.c_void_p(a.ctypes.data)) == 0
+        elif pinned and not persistent: W.host_unregister(d); W.host_unregister(q)
+        if pinned and "keep" in skip: kept.append((d, q))      # debugging: formerly registered arrays are never freed
+        if trace: print("   unregistered", file=sys.stderr, flush=True)
+        want = ref(t)
+        if trace: print("   reference frame done", file=sys.stderr, flush=True)
+        d2, q2 = r.read_maps()
+        if trace: print(f"   reference read-out done d2={d2.ctypes.data:#x} q2={q2.ctypes.data:#x}", file=sys.stderr, flush=True)
         bad += not (np.array_equal(got, want) and np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
     elif op < 0.60:
         b.compute_waves_async(t); last_t = t
@@ -61,7 +88,7 @@ for k in range(ops):
         bad += not (np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
     elif op < 0.74:
         b.set_frame_tracking(rng.random() < 0.5)
-    elif op < 0.75:
+    elif op < 0.75 and "merge" not in skip:
         b.set_merged_xpass(rng.random() < 0.7)       # (round 5/6: in-launch hand-offs on / off; same bits)
     elif op < 0.80:
         state["depth"] = rng.choice([1, 2, 3, 5]); b.set_pipeline_depth(state["depth"])
@@ -73,7 +100,7 @@ for k in range(ops):
         state["seed"] = rng.randrange(1 << 30); reprepare(); last_t = None
     elif op < 0.93:
         n = rng.choice(sizes); b.set_tile_size(n); r.set_tile_size(n)
-        b.set_placement_search(rng.choice([0, 1, 3])); reprepare(); last_t = None      # (round 6: Prepare's placement search on / off / forced at any size)
+        b.set_placement_search(1 if "search" in skip else rng.choice([0, 1, 3])); reprepare(); last_t = None      # (round 6: Prepare's placement search on / off / forced at any size)
     elif op < 0.94:
         what = rng.randrange(6)
         if what == 0: state["inter"] = rng.choice([16, 32])
@@ -119,6 +146,8 @@ for k in range(ops):
     if bad:
         print("MISMATCH at operation", k, "state", state, "n", n); break
 b.synchronize()
+for pair in pool.values():
+    for a in pair: W.host_unregister(a)
 print(f"soak_api: {ops} operations, {checked} checks, {'all identical' if not bad else 'FAILED'}")
 b.close(); r.close()
 sys.exit(1 if bad else 0)
