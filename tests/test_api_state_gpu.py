@@ -634,3 +634,45 @@ def test_host_register_round_trip():
     d2, q2 = b.read_maps()
     assert np.array_equal(d, d2) and np.array_equal(q, q2)
     b.close()
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_compute_waves_read_in_every_mode_and_binding(n):
+    """ocean_compute_waves_read in the configurations the size sweep above leaves out: every mode (the x passes' host stores are written per
+    role: HEIGHT1 emits zero slopes / displacements, JACOBIAN a fourth channel), half2 intermediates, the 16-bit spectrum, per-tile time
+    offsets, a caller-owned stream and caller-bound output maps -- page-locked destinations (direct stores at 256^2, engine copies at
+    1024^2) and pageable ones; always the bits ocean_compute_waves + ocean_read_maps deliver."""
+    import torch
+    import watersurfacerendering_amd as W
+    from watersurfacerendering_amd import _abi as A
+    tiles = 2
+    d = pinned_array((tiles, n, n, 4), np.float32, tag="d"); q = pinned_array((tiles, n, n, 4), np.float32, tag="q")
+
+    def check(b, what):
+        for t in (0.0, 2.5):
+            a0 = b.compute_waves(t).copy(); d0, q0 = b.read_maps()
+            a, _, _ = b.compute_waves_read(t, d, q)
+            assert np.array_equal(a, a0) and np.array_equal(d, d0) and np.array_equal(q, q0), (what, t, "page-locked")
+            a, dp, qp = b.compute_waves_read(t)
+            assert np.array_equal(a, a0) and np.array_equal(dp, d0) and np.array_equal(qp, q0), (what, t, "pageable")
+
+    b = W.OceanBatch(n, tiles, 0)
+    for mode in (A.OCEAN_MODE_FULL7, A.OCEAN_MODE_CHOPPY5, A.OCEAN_MODE_HEIGHT1, A.OCEAN_MODE_JACOBIAN):
+        b.set_mode(mode); b.prepare(SEED + 31)
+        check(b, f"mode {mode}")
+    b.set_mode(A.OCEAN_MODE_FULL7)
+    b.set_intermediate_precision(16); b.prepare(SEED + 31); check(b, "half2 intermediates")
+    b.set_intermediate_precision(32); b.set_spectrum_precision(16); b.prepare(SEED + 31); check(b, "16-bit spectrum")
+    b.set_spectrum_precision(32); b.set_time_offsets([0.0, 3.5]); b.prepare(SEED + 31); check(b, "time offsets")
+    b.set_time_offsets(None)
+    s = torch.cuda.Stream()
+    b.set_stream(s.cuda_stream); b.prepare(SEED + 31); check(b, "caller's stream")
+    b.set_stream(None)
+    maps = torch.zeros((2, tiles, n, n, 4), dtype=torch.float32, device="cuda:0")
+    b.bind_output(maps[0].data_ptr(), maps[1].data_ptr()); b.prepare(SEED + 31); check(b, "bound output")
+    a, _, _ = b.compute_waves_read(1.0, d, q)
+    torch.cuda.synchronize()
+    assert np.array_equal(maps[0].cpu().numpy(), d) and np.array_equal(maps[1].cpu().numpy(), q)       # the device copy stays complete
+    b.bind_output(None, None)
+    assert b.fault_recoveries == 0
+    b.close()
