@@ -44,8 +44,10 @@ int ocean_set_merged_xpass(ocean_t* ctx, int on);
  * context's life (profiles/r06_slow_window.txt) -- so ocean_prepare, like the reference's Prepare with its FFTW_MEASURE plans
  * (WSTessendorf.cpp:191-232), measures: from 1024 x 1024 up it allocates a few candidate copies of that buffer group, times serial frames on
  * each and keeps the fastest (6 candidates, ~45 ms at 2048 x 2048; frames are bit-identical wherever the buffers are).  trials = 0: the
- * library's rule; 1: off; n: that many candidates at any size.  Takes effect at the next ocean_prepare.  ocean_placement_report: what the most
- * recent ocean_prepare did -- candidates timed (0: none) and the serial frame time of the chosen and of the slowest candidate (us).         */
+ * library's rule; 1: off; n: that many candidates at any size.  Takes effect at the next ocean_prepare.  The search runs ONCE per allocation:
+ * a repeated ocean_prepare on the same buffers keeps the placement (and the report); a resize, or another `trials`, searches again.
+ * ocean_placement_report: what that search did -- candidates timed (0: none) and the serial frame time of the chosen and of the slowest
+ * candidate (us).                                                                                                                            */
 int ocean_set_placement_search(ocean_t* ctx, int trials);
 int ocean_placement_report(const ocean_t* ctx, int* trials, float* us_chosen, float* us_worst);
 

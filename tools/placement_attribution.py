@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Round 6: WHICH buffer's placement makes a context slow.  ocean_prepare's placement search with only some of the buffers differing between
 candidates (developer switch OCEAN_PLACEMENT_MASK: bit 0 spectrum, 1-2 dispersion, 3-5 chain 0's intermediates, 6 its maps) and every
-candidate's serial frame time printed (OCEAN_PLACEMENT_TRACE): the mask whose candidates spread like the all-buffers search is the culprit.
+candidate's serial frame time printed (OCEAN_PLACEMENT_TRACE; both switches exist in developer builds only: make -C watersurfacerendering_amd/csrc variant
+NAME=dev DEFS=-DOCEAN_DEVELOPER, then OCEAN_HIP_LIB=watersurfacerendering_amd/libocean_hip_dev.so): the mask whose candidates spread like the all-buffers search is the culprit.
     python3 tools/placement_attribution.py [N] [tiles] [candidates] [repeats]"""
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 6: do the slow allocations miss more in the address-translation caches?  One 2048^2 context whose Prepare times 12 candidate placements
-(OCEAN_PLACEMENT_TRACE prints their serial frame times); run under `rocprofv3 --pmc <translation counters>` the per-dispatch counters of the
+(OCEAN_PLACEMENT_TRACE prints their serial frame times: a developer build, -DOCEAN_DEVELOPER, through OCEAN_HIP_LIB); run under `rocprofv3 --pmc <translation counters>` the per-dispatch counters of the
 z pass can be grouped by candidate afterwards (tools/placement_tlb.py --summarise <counter_collection.csv>: the last 12 x 48 z-pass dispatches).
     rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum --output-format csv -d out -- python3 tools/placement_tlb.py"""
 import csv

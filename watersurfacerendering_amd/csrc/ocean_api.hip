@@ -66,7 +66,7 @@ static void free_device(ocean_ctx* c)
     c->k1d = nullptr; c->tw = nullptr;
     c->toff = nullptr; c->lambda = nullptr; c->tparams = nullptr; c->xi = nullptr;
     c->h0h = nullptr; c->h0_inv_scale = nullptr; c->h0_maxbits = nullptr; c->zscale = nullptr; c->zbounds = nullptr;
-    c->prepared = false;
+    c->prepared = false; c->placement_done = false;
     // nothing of the old buffers may be referred to any more: no frame, no chain to read out, no mips of the old size
     c->have_frame = false; c->last_set = 0; c->frame_ctr = 0; c->mips_ready = false; c->grid_vertices = 0;
     c->maps_shared = false;             // the exported / handed-out maps are gone with the buffers
@@ -689,6 +689,9 @@ static int enqueue_frame(ocean_ctx* c, float t, bool pipelined, hipEvent_t* mark
 // output) or the group is not the usual one (fp16 copy of the spectrum).
 static int placement_search(ocean_ctx* c)
 {
+    // once per allocation: a placement keeps its speed for as long as it lives, so a repeated Prepare on the same buffers (a parameter change
+    // in the reference's GUI) costs nothing extra and keeps the first search's report; a resize or a new candidate count searches again
+    if (c->placement_done) return OCEAN_OK;
     c->placement_tried = 0; c->placement_us_chosen = c->placement_us_worst = 0.0f;
     const size_t n = c->n, n2 = n * n, t = c->tiles;
     const size_t nu = n / 2 + 1, nup = (n / 2 + 16) & ~(size_t)15;
@@ -697,15 +700,20 @@ static int placement_search(ocean_ctx* c)
                               t * nu * nup * sizeof(float2), t * nup * n * sizeof(float), c->maps_bytes[0]};
     // which of them differ between candidates (developer switch for attribution runs: tools/placement_probe.py)
     unsigned mask = c->tune.placement_mask;
+    bool trace = false;
+#ifdef OCEAN_DEVELOPER      // A/B builds only (make variant ... DEFS=-DOCEAN_DEVELOPER): the shipped library reads no environment
     if (const char* e = std::getenv("OCEAN_PLACEMENT_MASK")) mask = (unsigned)std::strtoul(e, nullptr, 0);
-    const bool trace = std::getenv("OCEAN_PLACEMENT_TRACE") != nullptr;
+    trace = std::getenv("OCEAN_PLACEMENT_TRACE") != nullptr;
+#endif
     mask &= (1u << NB) - 1;
     size_t group = 0;
     for (int b = 0; b < NB; ++b) if (mask >> b & 1) group += bytes[b];
     int trials = c->placement_override > 0 ? c->placement_override
                                            : ((c->n >= c->tune.placement_min_n && group <= c->tune.placement_max_group_bytes) ? c->tune.placement_trials : 1);
     if (trials > 16) trials = 16;
-    if (trials <= 1 || !mask || c->user || c->ext_disp || c->ext_nrm || c->h0_bits == 16) return OCEAN_OK;
+    if (trials <= 1 || !mask) { c->placement_done = true; return OCEAN_OK; }
+    if (c->user || c->ext_disp || c->ext_nrm || c->h0_bits == 16) return OCEAN_OK;          // (not now: a later Prepare may)
+    c->placement_done = true;
     { int rc_ = alloc_set(c, 0); if (rc_) return rc_; }
     hipStream_t st = stream_of(c, 0);
     struct Group { void* p[NB]; };
@@ -779,6 +787,7 @@ extern "C" {
 int ocean_set_placement_search(ocean_t* c, int trials)
 {
     if (!c || trials < 0) return OCEAN_E_INVALID;
+    if (trials != c->placement_override) c->placement_done = false;
     c->placement_override = trials;
     return OCEAN_OK;
 }

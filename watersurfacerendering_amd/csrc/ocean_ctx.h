@@ -144,6 +144,7 @@ struct ocean_ctx {
     bool handoff = false;           // set by launch_frame: the frame it has just enqueued uses an in-launch hand-off
     bool recovering = false;        // recover_fault is re-enqueueing (no recursion)
     int placement_override = 0;     // ocean_set_placement_search: 0 = the library's rule (OceanTuning), n >= 1 = that many candidates (1 = off)
+    bool placement_done = false;        // the search has run (or was found unnecessary) for the buffers this context holds now
     int placement_tried = 0;        // what the most recent ocean_prepare did: candidates timed (0: no search), and their serial frame times
     float placement_us_chosen = 0.0f, placement_us_worst = 0.0f;
     unsigned fault_recoveries = 0;  // recoveries after an in-launch wait gave up (ocean_fault_recoveries)
