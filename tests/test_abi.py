@@ -320,3 +320,13 @@ def test_export_and_tracking_fail_loudly_without_a_device(abi):
     assert L.ocean_comm_count(None, None, None) == abi.OCEAN_E_INVALID
     assert L.ocean_algorithmic_bytes_per_launch(None, 0) == 23 and L.ocean_algorithmic_bytes_per_launch(None, 1) == 28
     assert L.ocean_algorithmic_bytes_per_launch(None, 2) == 22 and L.ocean_algorithmic_bytes_per_launch(None, 3) == 0
+
+
+def test_shipped_library_reads_no_environment():
+    """Every A/B and attribution switch (OCEAN_* variables) lives behind -DOCEAN_DEVELOPER: the shipped library does not import getenv."""
+    import shutil
+    import subprocess
+    from watersurfacerendering_amd import _abi
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--undefined-only", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out, [l for l in out.splitlines() if "getenv" in l]
