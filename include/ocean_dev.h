@@ -42,7 +42,7 @@ int ocean_set_merged_xpass(ocean_t* ctx, int on);
 /* Placement search of ocean_prepare (round 6).  The speed of the frame's first pass depends on where the spectrum and the intermediates happen to
  * be allocated -- contexts created back to back in one process run the SAME 2048 x 2048 z pass in 19.8 ... 28.6 us, each stable for the
  * context's life (profiles/r06_slow_window.txt) -- so ocean_prepare, like the reference's Prepare with its FFTW_MEASURE plans
- * (WSTessendorf.cpp:191-232), measures: from 1024 x 1024 up it allocates a few candidate copies of that buffer group, times serial frames on
+ * (WSTessendorf.cpp:191-232), measures: from 2048 x 2048 up it allocates a few candidate copies of that buffer group, times serial frames on
  * each and keeps the fastest (6 candidates, ~45 ms at 2048 x 2048; frames are bit-identical wherever the buffers are).  trials = 0: the
  * library's rule; 1: off; n: that many candidates at any size.  Takes effect at the next ocean_prepare.  The search runs ONCE per allocation:
  * a repeated ocean_prepare on the same buffers keeps the placement (and the report); a resize, or another `trials`, searches again.

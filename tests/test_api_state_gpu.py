@@ -568,9 +568,9 @@ def test_compute_waves_read_is_compute_waves_plus_read_maps(n, tiles, depth):
 
 
 def test_placement_search_changes_no_bit_and_reports():
-    """ocean_prepare's placement search (round 6; include/ocean_dev.h): from 1024^2 up Prepare times a few candidate allocations of the spectrum +
+    """ocean_prepare's placement search (round 6; include/ocean_dev.h): from 2048^2 up Prepare times a few candidate allocations of the spectrum +
     intermediates on serial frames and keeps the fastest -- the same 2048^2 z pass runs 19.8 ... 28.6 us depending on where those buffers landed
-    (profiles/r06_slow_window.txt).  Frames do not depend on it bit for bit; the report says what was done; below 1024^2 nothing is searched
+    (profiles/r06_slow_window.txt).  Frames do not depend on it bit for bit; the report says what was done; below 2048^2 nothing is searched
     unless asked for; the calibration frames leave nothing to read out; a repeated Prepare on the same buffers does not search again."""
     import watersurfacerendering_amd as W
     from watersurfacerendering_amd import _abi as A
@@ -581,7 +581,7 @@ def test_placement_search_changes_no_bit_and_reports():
             b.set_placement_search(trials)
             b.prepare(SEED + 31)
             tried, chosen, worst = b.placement_report()
-            if trials == 1:
+            if trials == 1 or (trials == 0 and n < 2048):
                 assert (tried, chosen, worst) == (0, 0.0, 0.0)
             else:
                 assert tried == (6 if trials == 0 else 9) and 0.0 < chosen <= worst < 10.0 * chosen, (n, tiles, trials, tried, chosen, worst)

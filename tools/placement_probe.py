@@ -2,7 +2,7 @@
 """Round 6: what ocean_prepare's placement search buys.  Contexts created one after the other in ONE process (all alive), alternately without
 and with the search; per context the serial z pass / frame time (dispatch-attached events, 300 frames behind 60 ms of load) and the search's
 own report.  Without it a context's speed is whatever its allocation drew; with it every context should sit at the fast end.
-    python3 tools/placement_probe.py [N] [contexts]"""
+    python3 tools/placement_probe.py [N] [contexts] [tiles] [candidates when on: 0 = the library's rule]"""
 import os
 import sys
 import time
@@ -13,12 +13,14 @@ import watersurfacerendering_amd as W  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+tiles = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+forced = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 alive = []
 rows = {0: [], 1: []}
 for k in range(count):
     on = k % 2
-    b = W.OceanBatch(n, 1, 0)
-    b.set_placement_search(0 if on else 1)
+    b = W.OceanBatch(n, tiles, 0)
+    b.set_placement_search(forced if on else 1)
     t0 = time.perf_counter()
     b.prepare(0x5EED0000 + k)
     prep_ms = (time.perf_counter() - t0) * 1e3

@@ -60,7 +60,7 @@ struct OceanTuning {
     // (all held at once, so that they ARE different memory) on serial frames and keeps the fastest.  From this tile size up, while one group
     // stays below the byte bound; ocean_set_placement_search(ctx, n) overrides (1 = off).
     int placement_trials = 6;
-    unsigned placement_min_n = 1024;
+    unsigned placement_min_n = 2048;            // (1024^2 and batches of smaller tiles: contexts differ by 2-7 %, the search buys 0.5-1.3 %: profiles/r06_slow_window.txt item 10)
     size_t placement_max_group_bytes = (size_t)512 << 20;
     unsigned placement_mask = 0x1f;               // which buffers differ between candidates: bit 0 spectrum, 1-2 dispersion, 3-5 chain 0's intermediates, 6 its maps
     // Merged x pass / one-launch frame (in-launch hand-offs): only where every workgroup of the grid has a compute unit to itself
