@@ -46,8 +46,11 @@ void* pinned_device_address(const void* host_ptr, size_t bytes)
         for (const PinnedRange& r : g_pinned)
             if (h >= r.host && h + bytes <= r.host + r.bytes) return r.dev + (h - r.host);
     }
-    void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host_ptr), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // page-locked by other means: the runtime knows -- and the WHOLE range must be (its last byte one linear mapping away from its first)
+    void *dp = nullptr, *dp_last = nullptr;
+    if (bytes == 0 || hipHostGetDevicePointer(&dp, const_cast<void*>(host_ptr), 0) != hipSuccess ||
+        hipHostGetDevicePointer(&dp_last, const_cast<char*>(h) + (bytes - 1), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!dp || static_cast<char*>(dp_last) != static_cast<char*>(dp) + (bytes - 1)) return nullptr;
     return dp;
 }
 }  // namespace
