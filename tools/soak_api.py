@@ -12,7 +12,7 @@ import devlib  # noqa: F401  (OCEAN_HIP_LIB -> variant library, developer A/B on
 import watersurfacerendering_amd as W
 ops = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-sizes = [64, 256, 512, 1024]
+sizes = [int(x) for x in os.environ.get("SOAK_SIZES", "64,256,512,1024").split(",")]
 n, tiles = 256, 2
 b = W.OceanBatch(n, tiles, 0); r = W.OceanBatch(n, tiles, 0)
 state = dict(mode=0, depth=1, lam=-1.0, seed=5, inter=32, spec=32, disp=(0, 0.0), wind=(20.0, 1.0, 0.5), length=1000.0, offs=None)
