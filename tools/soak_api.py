@@ -96,12 +96,12 @@ for k in range(ops):
         state["lam"] = rng.choice([-1.0, -0.5, -2.0]); b.set_lambda(state["lam"]); r.set_lambda(state["lam"]); last_t = None   # (takes effect at the next frame)
     elif op < 0.90:
         state["mode"] = rng.choice([0, 0, 3, 1, 2]); b.set_mode(state["mode"]); r.set_mode(state["mode"]); last_t = None
-    elif op < 0.92:
+    elif op < 0.92 and "reprepare" not in skip:
         state["seed"] = rng.randrange(1 << 30); reprepare(); last_t = None
-    elif op < 0.93:
+    elif op < 0.93 and "resize" not in skip:
         n = rng.choice(sizes); b.set_tile_size(n); r.set_tile_size(n)
         b.set_placement_search(1 if "search" in skip else rng.choice([0, 1, 3])); reprepare(); last_t = None      # (round 6: Prepare's placement search on / off / forced at any size)
-    elif op < 0.94:
+    elif op < 0.94 and "reprepare" not in skip:
         what = rng.randrange(6)
         if what == 0: state["inter"] = rng.choice([16, 32])
         elif what == 1: state["spec"] = rng.choice([16, 32])
@@ -110,7 +110,7 @@ for k in range(ops):
         elif what == 4: state["length"] = rng.choice([250.0, 1000.0, 3000.0])
         else: state["offs"] = rng.choice([None, [0.25 * i for i in range(tiles)]])
         reprepare(); last_t = None
-    elif op < 0.945:
+    elif op < 0.945 and "fresh" not in skip:
         fresh_reference()
     elif op < 0.955 and last_t is not None:
         tile = rng.randrange(tiles)
@@ -135,9 +135,9 @@ for k in range(ops):
         b.read_maps_async(d, q); b.synchronize()
         ref(last_t); d2, q2 = r.read_maps()
         bad += not (np.array_equal(d, d2) and np.array_equal(q, q2)); checked += 1
-    elif op < 0.985 and last_t is not None and state["depth"] == 1:
+    elif op < 0.985 and last_t is not None and state["depth"] == 1 and "export" not in skip:
         fd = b.export_maps()[0]; os.close(fd)
-    elif op < 0.99:
+    elif op < 0.99 and "select" not in skip:
         b.select_streams(3); last_t = None          # streams re-ordered; the maps hold a calibration frame
     elif last_t is not None:
         h = [b.heights(i) for i in range(tiles)]
