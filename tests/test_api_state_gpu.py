@@ -623,10 +623,11 @@ def test_placement_search_changes_no_bit_and_reports():
     b.close()
 
 
+@isolated
 def test_host_register_round_trip():
     """ocean_host_register / ocean_host_unregister on a small page-aligned range: both succeed once, the second unregistration is refused by
     the runtime (reported, not fatal), and the library's own list of ranges forgets the entry (no stale device address is handed out).  The one
-    place in the suite that unregisters: see conftest.pinned_array."""
+    place in the suite that unregisters -- in a process of its own: see conftest.pinned_array."""
     import watersurfacerendering_amd as W
     from watersurfacerendering_amd import _abi as A
     L = A.lib()
