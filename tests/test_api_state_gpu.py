@@ -689,31 +689,38 @@ def test_compute_waves_read_in_every_mode_and_binding(n):
     b.close()
 
 
-_PARTLY_REGISTERED = []
-
-
 def test_compute_waves_read_with_memory_page_locked_elsewhere():
     """Destinations page-locked by other means than ocean_host_register: a pinned torch tensor (hipHostMalloc) takes the direct-store path through
-    the runtime's lookup; an array of which only the first half is registered must NOT -- the x passes would store past the mapping --: the call
-    goes to the copy engines, whose copy the runtime refuses (reported; no fault; the context goes on)."""
-    import ctypes as C
+    the runtime's lookup.  Same bits as call + read-out."""
     import torch
     import watersurfacerendering_amd as W
     n, tiles = 256, 2
     b = W.OceanBatch(n, tiles, 0); b.prepare(SEED + 41)
     a0 = b.compute_waves(0.75).copy(); d0, q0 = b.read_maps()
     td = torch.empty((tiles, n, n, 4), dtype=torch.float32, pin_memory=True); tq = torch.empty_like(td, pin_memory=True)
-    a, _, _ = b.compute_waves_read(0.75, td.numpy(), tq.numpy())
-    assert np.array_equal(a, a0) and np.array_equal(td.numpy(), d0) and np.array_equal(tq.numpy(), q0)
+    for t in (0.75, 0.75):
+        a, _, _ = b.compute_waves_read(t, td.numpy(), tq.numpy())
+        assert np.array_equal(a, a0) and np.array_equal(td.numpy(), d0) and np.array_equal(tq.numpy(), q0)
+    assert b.fault_recoveries == 0
+    b.close()
+
+
+@isolated
+def test_compute_waves_read_refuses_a_partly_registered_destination():
+    """An array of which only the first half is page-locked must NOT take the direct-store path -- the x passes would store past the mapping --:
+    the call goes to the copy engines, whose copy the runtime refuses (a destination that straddles registered and unregistered memory);
+    reported, nothing faults, the context goes on.  In a process of its own: it leaves a half-registered allocation behind."""
+    import ctypes as C
+    import watersurfacerendering_amd as W
+    n, tiles = 256, 2
+    b = W.OceanBatch(n, tiles, 0); b.prepare(SEED + 41)
+    a0 = b.compute_waves(0.75).copy(); d0, q0 = b.read_maps()
     hip = C.CDLL("libamdhip64.so")
     raw = np.zeros(tiles * n * n * 16 + 8192, dtype=np.uint8)
     o = (-raw.ctypes.data) % 4096
     d = raw[o:o + tiles * n * n * 16].view(np.float32).reshape(tiles, n, n, 4)
-    assert hip.hipHostRegister(C.c_void_p(d.ctypes.data), C.c_size_t(d.nbytes // 2), 0) == 0       # the first half only; stays registered (no churn)
-    _PARTLY_REGISTERED.append(raw)
+    assert hip.hipHostRegister(C.c_void_p(d.ctypes.data), C.c_size_t(d.nbytes // 2), 0) == 0       # the first half only; stays registered
     q = np.empty_like(d0)
-    # ... the runtime then refuses the copy itself (a destination that straddles registered and unregistered memory): reported, nothing
-    # faults, the context goes on
     for dst in ((d, q), (q, d)):
         with pytest.raises(W.OceanError) as e:
             b.compute_waves_read(0.75, *dst)
@@ -721,7 +728,5 @@ def test_compute_waves_read_with_memory_page_locked_elsewhere():
     b.synchronize()
     a, dd, qq = b.compute_waves_read(0.75)
     assert np.array_equal(a, a0) and np.array_equal(dd, d0) and np.array_equal(qq, q0)
-    a, _, _ = b.compute_waves_read(0.75, td.numpy(), tq.numpy())
-    assert np.array_equal(a, a0) and np.array_equal(td.numpy(), d0) and np.array_equal(tq.numpy(), q0)
     assert b.fault_recoveries == 0
     b.close()

@@ -202,6 +202,7 @@ static int drain_streams(ocean_ctx* c)
         if (c->own[i]) HIP_TRY(hipStreamSynchronize(c->own[i]));
     if (c->user) HIP_TRY(hipStreamSynchronize(c->user));
     if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));     // (ocean_compute_waves_read's normal-map copies)
     return OCEAN_OK;
 }
 static int recover_fault(ocean_ctx* c)
@@ -337,6 +338,9 @@ void ocean_destroy(ocean_t* c)
     for (auto& e : c->end_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->z_done) if (e) (void)hipEventDestroy(e);
     for (auto& row : c->mark_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+    if (c->nrm_final) (void)hipEventDestroy(c->nrm_final);
+    for (auto& e : c->copy_done) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (int i = 0; i < MAXD; ++i)
         if (c->own[i]) (void)hipStreamDestroy(c->own[i]);
     delete c;
@@ -979,11 +983,19 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
             nst = c->copy_stream;
         }
         HIP_TRY(hipMemcpyAsync(nrm, q, bytes, hipMemcpyDeviceToHost, nst));
-        HIP_TRY(hipEventRecord(c->copy_done[0], nst));
-        HIP_TRY(hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st));
+        hipError_t ce = hipEventRecord(c->copy_done[0], nst);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(disp, d, bytes, hipMemcpyDeviceToHost, st);
+        if (ce != hipSuccess) {         // no copy into the caller's memory may be in flight when the call returns with an error
+            g_last_hip = (int)ce; (void)hipGetLastError();
+            (void)hipStreamSynchronize(nst); (void)hipStreamSynchronize(st);
+            return ce == hipErrorOutOfMemory ? OCEAN_E_NOMEM : OCEAN_E_HIP;
+        }
     }
     // (direct stores: the event behind the frame's last kernel says that its stores -- the host's included -- have been released)
-    HIP_TRY(hipEventRecord(c->copy_done[1], st));
+    if (hipError_t ee = hipEventRecord(c->copy_done[1], st); ee != hipSuccess) {
+        g_last_hip = (int)ee; (void)hipGetLastError(); (void)hipStreamSynchronize(nst); (void)hipStreamSynchronize(st);
+        return OCEAN_E_HIP;
+    }
     rc = wait_frame(c, set);        // the frame's completion records (a poll): A, min, max -- the maps may still be on their way
     if (rc == OCEAN_OK && c->fault_recoveries_seen != c->fault_recoveries) {
         // the frame was run again (an in-launch wait had given up): what reached the host may be the wrong frame's -- copy again, plainly
@@ -1001,7 +1013,7 @@ int ocean_compute_waves_read(ocean_t* c, float t, float* out_amp, float* disp, f
         for (;;) {
             const hipError_t e = hipEventQuery(c->copy_done[k]);
             if (e == hipSuccess) break;
-            if (e != hipErrorNotReady) { g_last_hip = (int)e; return OCEAN_E_HIP; }
+            if (e != hipErrorNotReady) { g_last_hip = (int)e; (void)hipGetLastError(); (void)hipStreamSynchronize(nst); (void)hipStreamSynchronize(st); return OCEAN_E_HIP; }
             if ((++spins & 255u) == 0 && clock::now() - t0 > std::chrono::milliseconds(50)) { HIP_TRY(hipEventSynchronize(c->copy_done[k])); break; }
             __builtin_ia32_pause();
         }
